@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  Imports the reference's
+``ClassifierFreeDiffRoll`` through oracle/ref_import.py (stub modules for the missing
+third-party packages), drives it on seeded inputs and stores inputs + outputs as small
+.npz files.  Weights are seeded synthetic ones (oracle.diffroll_ref.synthetic_params);
+fixtures store the seed plus a checksum of the weights rather than the weights.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import diffroll_ref as R          # noqa: E402
+from oracle import ref_import as RI           # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def hp_small(k, C=32, L=3, S=8, hop=512, n_fft=2048):
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=C, residual_layers=L, kernel_size=k, timesteps=S,
+              hop_length=hop, n_fft=n_fft)
+    return hp
+
+
+def weight_checksum(params):
+    return float(sum(v.double().abs().sum().item() for v in params.values()))
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} kB")
+
+
+def gen_schedule():
+    for S in (50, 200):
+        m = RI.build_reference(hp_small(3, S=S), "cfdg_ddpm_x0", 0.5)
+        save(f"schedule_{S}", betas=m.betas, alphas=m.alphas,
+             sqrt_recip_alphas=m.sqrt_recip_alphas, sqrt_alphas_cumprod=m.sqrt_alphas_cumprod,
+             sqrt_one_minus_alphas_cumprod=m.sqrt_one_minus_alphas_cumprod,
+             posterior_variance=m.posterior_variance,
+             embedding=m.diffusion_embedding.embedding)
+
+
+def gen_frontend():
+    """Front-end outputs as returned by the reference forward() (2nd return value)."""
+    hp = hp_small(3)
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+    params = R.synthetic_params(hp, seed=1)
+    RI.load_params(m, params)
+    torch.manual_seed(10)
+    L = 8192
+    T = L // hp["hop_length"]
+    wav_rand = 0.1 * torch.randn(2, L)
+    n = torch.arange(L, dtype=torch.float64)
+    wav_sine = (0.5 * torch.sin(2 * np.pi * 440.0 * n / 16000.0)).float()[None]
+    wav_zero = torch.zeros(1, L)
+    wav = torch.cat([wav_rand, wav_sine, wav_zero], 0)        # (4, L)
+    x = torch.randn(4, 1, T, 88)
+    t = torch.tensor(3).repeat(4)
+    with torch.no_grad():
+        _, spec = m(x, wav, t)
+        _, spec_t = m(x, wav, t, inpainting_t=[4, 9])
+        _, spec_f = m(x, wav, t, inpainting_f=[20, 100])
+        _, spec_tf = m(x, wav, t, inpainting_t=[4, 9], inpainting_f=[20, 100])
+        _, spec_u = m(x, wav, t, sampling=True)
+        mel_raw = m.mel_layer(wav)
+    save("frontend", hp=json.dumps(hp), wav=wav, T=T, spec=spec, spec_t=spec_t, spec_f=spec_f,
+         spec_tf=spec_tf, spec_u=spec_u, mel_raw=mel_raw)
+
+
+def gen_forward():
+    for k in (3, 9, 15):
+        hp = hp_small(k, C=32, L=5)
+        m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+        params = R.synthetic_params(hp, seed=100 + k)
+        RI.load_params(m, params)
+        torch.manual_seed(20 + k)
+        B, L = 3, 40 * 512
+        T = 40
+        wav = 0.1 * torch.randn(B, L)
+        x = torch.randn(B, 1, T, 88)
+        t = torch.tensor(5).repeat(B)
+        with torch.no_grad():
+            x0_c, spec = m(x, wav, t)
+            x0_u, _ = m(x, torch.zeros_like(wav), t, sampling=True)
+            x0_i, spec_i = m(x, wav, t, inpainting_t=[10, 20])
+        save(f"forward_k{k}", hp=json.dumps(hp), seed=100 + k, wsum=weight_checksum(params),
+             wav=wav, x=x, t=5, x0_c=x0_c, x0_u=x0_u, x0_i=x0_i, spec=spec, spec_i=spec_i)
+
+    # one full-width case: C=512, k=9, 4 layers (dilations 1,2,4,8), T=80
+    hp = hp_small(9, C=512, L=4)
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+    params = R.synthetic_params(hp, seed=777)
+    RI.load_params(m, params)
+    torch.manual_seed(31)
+    B, T = 2, 80
+    wav = 0.1 * torch.randn(B, T * 512)
+    x = torch.randn(B, 1, T, 88)
+    t = torch.tensor(2).repeat(B)
+    with torch.no_grad():
+        x0_c, spec = m(x, wav, t)
+        x0_u, _ = m(x, torch.zeros_like(wav), t, sampling=True)
+    save("forward_wide_k9", hp=json.dumps(hp), seed=777, wsum=weight_checksum(params),
+         wav=wav, x=x, t=2, x0_c=x0_c, x0_u=x0_u)
+
+
+def gen_steps_and_chain():
+    S = 8
+    hp = hp_small(9, C=32, L=5, S=S)
+    params = R.synthetic_params(hp, seed=555)
+    B, T = 2, 24
+    torch.manual_seed(41)
+    wav = 0.1 * torch.randn(B, T * 512)
+    x = torch.randn(B, 1, T, 88)
+    noise = torch.randn(S, B, 1, T, 88)
+    arrays = dict(hp=json.dumps(hp), seed=555, wsum=weight_checksum(params), wav=wav, x=x,
+                  noise=noise, w=0.5, inpainting_t=np.array([6, 12]))
+    for sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0", "generation_ddpm_x0", "ddpm_x0"):
+        it = [6, 12] if sampler == "inpainting_ddpm_x0" else None
+        m = RI.build_reference(hp, sampler, 0.5, inpainting_t=it)
+        RI.load_params(m, params)
+        with torch.no_grad():
+            for t_index in (S - 1, 1, 0):
+                with RI.injected_noise([noise[t_index]]):
+                    out, _ = m.reverse_diffusion(x, wav, t_index)
+                arrays[f"{sampler}_t{t_index}"] = out
+            # full chain t = S-1 .. 0 (loop of task/diffusion.py:528-534)
+            xx = x
+            with RI.injected_noise([noise[t] for t in reversed(range(1, S))]):
+                for t_index in reversed(range(S)):
+                    xx, _ = m.reverse_diffusion(xx, wav, t_index)
+            arrays[f"{sampler}_chain"] = xx
+    save("steps_chain_k9", **arrays)
+
+
+if __name__ == "__main__":
+    assert RI.reference_available(), "needs /root/reference"
+    torch.set_num_threads(8)
+    gen_schedule()
+    gen_frontend()
+    gen_forward()
+    gen_steps_and_chain()
