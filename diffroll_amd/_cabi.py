@@ -1,0 +1,89 @@
+"""ctypes binding of the C-ABI in include/diffroll_amd.h (the only way Python reaches the kernels).
+
+There is deliberately no fallback: if the shared library is missing or no MI355X is visible the
+calls raise - a silent CPU path would void every parity and performance claim.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffroll_amd.so")
+
+DR_ABI_VERSION = 1
+DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
+
+SAMPLERS = {
+    "ddpm_x0": 0,
+    "cfdg_ddpm_x0": 1,
+    "generation_ddpm_x0": 2,
+    "inpainting_ddpm_x0": 3,
+}
+COND_SPEC, COND_UNCOND = 0, 1
+
+# every symbol include/diffroll_amd.h declares
+EXPORTS = [
+    "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
+    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_profile_enable",
+    "dr_profile_read", "dr_bench_layer",
+]
+
+
+class DrConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32),
+        ("residual_channels", C.c_int32), ("residual_layers", C.c_int32),
+        ("kernel_size", C.c_int32), ("dilation_base", C.c_int32), ("dilation_bound", C.c_int32),
+        ("n_mels", C.c_int32), ("timesteps", C.c_int32), ("sample_rate", C.c_int32),
+        ("n_fft", C.c_int32), ("hop_length", C.c_int32),
+        ("f_min", C.c_float), ("f_max", C.c_float), ("beta_start", C.c_float), ("beta_end", C.c_float),
+    ]
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the engine and declare the prototypes.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build the HIP extension first (python -m diffroll_amd.build). "
+            "diffroll_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, f32p = C.c_void_p, C.POINTER(C.c_float)
+    lib.dr_abi_version.restype = C.c_int
+    lib.dr_abi_version.argtypes = []
+    lib.dr_create.restype = C.c_int
+    lib.dr_create.argtypes = [C.POINTER(vp), C.POINTER(DrConfig)]
+    lib.dr_destroy.restype = None
+    lib.dr_destroy.argtypes = [vp]
+    lib.dr_last_error.restype = C.c_char_p
+    lib.dr_last_error.argtypes = [vp]
+    lib.dr_set_param.restype = C.c_int
+    lib.dr_set_param.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
+    lib.dr_set_tables.restype = C.c_int
+    lib.dr_set_tables.argtypes = [vp, f32p, f32p]
+    lib.dr_commit.restype = C.c_int
+    lib.dr_commit.argtypes = [vp, vp]
+    lib.dr_frontend.restype = C.c_int
+    lib.dr_frontend.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.dr_forward.restype = C.c_int
+    lib.dr_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.dr_step.restype = C.c_int
+    lib.dr_step.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, vp]
+    lib.dr_sample.restype = C.c_int
+    lib.dr_sample.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, vp]
+    lib.dr_profile_enable.restype = C.c_int
+    lib.dr_profile_enable.argtypes = [vp, C.c_int]
+    lib.dr_profile_read.restype = C.c_int
+    lib.dr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]
+    lib.dr_bench_layer.restype = C.c_int
+    lib.dr_bench_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    if lib.dr_abi_version() != DR_ABI_VERSION:
+        raise RuntimeError("libdiffroll_amd.so ABI version mismatch: rebuild it")
+    _lib = lib
+    return lib

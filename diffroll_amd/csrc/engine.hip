@@ -1,0 +1,766 @@
+// Host side of the DiffRoll sampling engine: weight packing, hoisted tables, per-step launch
+// sequences, hipGraph capture of the reverse chain, and the C-ABI of include/diffroll_amd.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/diffroll_amd.h"
+#include "kernels.h"
+
+using namespace dr;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct LayerW {
+    float* conv_w = nullptr;     // packed (paired rows) [MTc][kch][k] slabs
+    float* conv_b = nullptr;     // packed-row bias (conditional samples; cond tensor carries bc)
+    float* conv_b_u = nullptr;   // packed-row bias for unconditional samples: b_conv + (bc - sum_m Wc)
+    float* out_w = nullptr;      // packed (natural halves) 1x1
+    float* out_b = nullptr;
+    float* cond_w = nullptr;     // packed (paired rows) conditioner 1x1
+    float* cond_b = nullptr;
+    int dil = 1;
+};
+
+struct GraphKey {
+    int sampler = -1, B = 0, T = 0, first_sample = 0;
+    float* x = nullptr;
+    const float* noise = nullptr;
+    float w = 0.f;
+    uint64_t seed = 0;
+    bool operator==(const GraphKey& o) const {
+        return sampler == o.sampler && B == o.B && T == o.T && first_sample == o.first_sample && x == o.x &&
+               noise == o.noise && w == o.w && seed == o.seed;
+    }
+};
+
+}  // namespace
+
+struct dr_engine {
+    dr_config cfg{};
+    int C = 0, Cp = 0, L = 0, K = 0, S = 0, NM = 0;
+    int n_bins = 0, bins_p = 0;          // n_fft/2+1 and its 64-multiple padding
+    std::string err;
+    std::map<std::string, std::vector<float>> params;
+    std::vector<float> h_emb, h_coef;
+    bool committed = false;
+
+    // device constants
+    float* d_coef = nullptr;   // (S,5)
+    float* d_dtab = nullptr;   // (S, L, Cp)   hoisted diffusion_projection(diffusion_embedding(t))
+    std::vector<LayerW> layers;
+    float *in_w = nullptr, *in_b = nullptr, *skip_w = nullptr, *skip_b = nullptr, *outp_w = nullptr, *outp_b = nullptr;
+    float *dft_w = nullptr, *mel_w = nullptr;
+    std::vector<void*> owned;   // every constant allocation, for dr_destroy
+
+    // activation workspace (sized for ws_NB samples x ws_T frames)
+    int ws_NB = 0, ws_T = 0;
+    float *h = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
+    // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
+    int fe_B = 0, fe_T = 0;
+    size_t cond_cap = 0;
+    float* cond = nullptr;
+    // front-end workspace
+    size_t fe_cap_wav = 0, fe_cap_pow = 0, fe_cap_log = 0, fe_cap_spec = 0, fe_cap_mm = 0;
+    float *wav_pad = nullptr, *power = nullptr, *logmel = nullptr, *specP4 = nullptr, *mm = nullptr;
+
+    // graph cache
+    GraphKey gkey;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
+
+    // profiling of the dominant kernel
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+namespace {
+
+int fail(dr_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(e, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _st = (expr);                                                                \
+        if (_st != hipSuccess)                                                                  \
+            return fail((e), DR_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_st),   \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- weight packing (layout: kernels.h) -------------------------------------------------------
+// get(prow, ch, tap) returns the (zero-padded) weight for packed row prow, input channel ch.
+template <class F>
+std::vector<float> pack_weights(int MT, int kchunks, int taps, F get) {
+    std::vector<float> out((size_t)MT * kchunks * taps * 4096);
+    size_t o = 0;
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kc = 0; kc < kchunks; ++kc)
+            for (int j = 0; j < taps; ++j)
+                for (int gq = 0; gq < 4; ++gq)
+                    for (int hi = 0; hi < 2; ++hi)
+                        for (int row = 0; row < 128; ++row)
+                            for (int i = 0; i < 4; ++i)
+                                out[o++] = get(mt * 128 + row, kc * 32 + gq * 8 + hi * 4 + i, j);
+    return out;
+}
+
+// paired row map: packed row -> (which half mi, channel c); 128-row tile = 2 wave-rows x {gate32, filter32}
+inline void paired_row(int prow, int& mi, int& c) {
+    const int mt = prow >> 7, rr = prow & 127;
+    const int wr = rr >> 6;
+    mi = (rr >> 5) & 1;
+    c = mt * 64 + wr * 32 + (rr & 31);
+}
+
+int upload(dr_engine* e, const std::vector<float>& v, float** out) {
+    void* p = nullptr;
+    HIPCHK(e, hipMalloc(&p, std::max<size_t>(v.size(), 4) * sizeof(float)));
+    e->owned.push_back(p);
+    HIPCHK(e, hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return DR_OK;
+}
+
+int dev_alloc(dr_engine* e, float** p, size_t floats, bool zero = true) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    void* q = nullptr;
+    HIPCHK(e, hipMalloc(&q, std::max<size_t>(floats, 4) * sizeof(float)));
+    if (zero) HIPCHK(e, hipMemset(q, 0, std::max<size_t>(floats, 4) * sizeof(float)));
+    *p = (float*)q;
+    return DR_OK;
+}
+
+const std::vector<float>* find_param(dr_engine* e, const std::string& name) {
+    auto it = e->params.find(name);
+    return it == e->params.end() ? nullptr : &it->second;
+}
+
+size_t expected_numel(const dr_engine* e, const std::string& name) {
+    const size_t C = e->C, K = e->K, NM = e->NM;
+    if (name == "input_projection.weight") return C * 88;
+    if (name == "input_projection.bias") return C;
+    if (name == "diffusion_embedding.projection1.weight") return 512 * 128;
+    if (name == "diffusion_embedding.projection1.bias") return 512;
+    if (name == "diffusion_embedding.projection2.weight") return 512 * 512;
+    if (name == "diffusion_embedding.projection2.bias") return 512;
+    if (name == "skip_projection.weight") return C * C;
+    if (name == "skip_projection.bias") return C;
+    if (name == "output_projection.weight") return 88 * C;
+    if (name == "output_projection.bias") return 88;
+    const std::string pre = "residual_layers.";
+    if (name.compare(0, pre.size(), pre) == 0) {
+        const size_t dot = name.find('.', pre.size());
+        if (dot == std::string::npos) return 0;
+        const int li = atoi(name.substr(pre.size(), dot - pre.size()).c_str());
+        if (li < 0 || li >= e->L) return 0;
+        const std::string rest = name.substr(dot + 1);
+        if (rest == "dilated_conv.weight") return 2 * C * C * K;
+        if (rest == "dilated_conv.bias") return 2 * C;
+        if (rest == "diffusion_projection.weight") return C * 512;
+        if (rest == "diffusion_projection.bias") return C;
+        if (rest == "conditioner_projection.weight") return 2 * C * NM;
+        if (rest == "conditioner_projection.bias") return 2 * C;
+        if (rest == "output_projection.weight") return 2 * C * C;
+        if (rest == "output_projection.bias") return 2 * C;
+    }
+    return 0;
+}
+
+int pick_ni(int taps, int dil) {
+    const int halo = ((taps - 1) / 2) * dil;
+    return (128 + 2 * halo <= 256) ? 2 : 1;
+}
+
+// common GemmArgs for a P4 activation input [NB][planes][T][4]
+GemmArgs p4_gemm(const float* Wp, const float* bias, int MT, const float* X, int planes, int NB, int T) {
+    GemmArgs a{};
+    a.Wp = Wp; a.bias = bias; a.MT = MT;
+    a.X = X; a.x_bs = (long)planes * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4; a.x_planes = planes;
+    a.kchunks = (planes + 7) / 8;
+    a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+    return a;
+}
+void p4_out(GemmArgs& a, float* Y, int planes, int T, int rows) {
+    a.Y = Y; a.y_bs = (long)planes * T * 4; a.y_ps = (long)T * 4; a.y_fs = 4; a.y_rows = rows;
+}
+
+int ensure_workspace(dr_engine* e, int NB, int T) {
+    if (NB <= e->ws_NB && T == e->ws_T) return DR_OK;
+    const int nb = std::max(NB, e->ws_T == T ? e->ws_NB : 0);
+    const size_t act = (size_t)nb * e->Cp * T;
+    int rc;
+    if ((rc = dev_alloc(e, &e->h, act))) return rc;
+    if ((rc = dev_alloc(e, &e->g, act))) return rc;
+    if ((rc = dev_alloc(e, &e->skip, act))) return rc;
+    if ((rc = dev_alloc(e, &e->tmp, act))) return rc;
+    if ((rc = dev_alloc(e, &e->x0buf, (size_t)nb * T * 88))) return rc;
+    e->ws_NB = nb;
+    e->ws_T = T;
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    e->gkey = GraphKey{};
+    return DR_OK;
+}
+
+// One network evaluation for NB samples (first n_cond conditional) at step t.
+//   xin (B,T,88) rows are used modulo bmod (classifier-free batching: 2B evaluations of B inputs).
+int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, int T, int t, float* x0_out,
+                hipStream_t st) {
+    const int Cp = e->Cp, P = Cp / 4, L = e->L;
+    // input projection + relu (model/diffwave.py:667-668)
+    {
+        GemmArgs a{};
+        a.Wp = e->in_w; a.bias = e->in_b; a.MT = (Cp + 127) / 128;
+        a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
+        a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+        p4_out(a, e->h, P, T, Cp);
+        HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
+    }
+    for (int l = 0; l < L; ++l) {
+        const LayerW& w = e->layers[l];
+        {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
+            GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->h, P, NB, T);
+            a.bias2 = w.conv_b_u;
+            a.dvec = e->d_dtab + ((size_t)t * L + l) * Cp;
+            a.taps = e->K; a.dil = w.dil;
+            a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : nullptr;
+            a.c_bs = (long)2 * Cp * T;
+            a.n_cond = n_cond;
+            p4_out(a, e->g, P, T, Cp);
+            const bool timed = e->prof && e->prof_used < e->prof_events.size();
+            if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
+            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(e->K, w.dil), st));
+            if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
+        }
+        {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
+            GemmArgs a = p4_gemm(w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+            p4_out(a, e->h, P, T, Cp);
+            a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
+            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, 2, st));
+        }
+    }
+    {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
+        GemmArgs a = p4_gemm(e->skip_w, e->skip_b, (Cp + 127) / 128, e->skip, P, NB, T);
+        a.alpha = (float)(1.0 / std::sqrt((double)L));
+        p4_out(a, e->tmp, P, T, Cp);
+        HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
+    }
+    {   // output projection, written straight into the (B,T,88) roll layout (:685-686)
+        GemmArgs a = p4_gemm(e->outp_w, e->outp_b, 1, e->tmp, P, NB, T);
+        a.Y = x0_out; a.y_bs = (long)T * 88; a.y_ps = 4; a.y_fs = 88; a.y_rows = 88;
+        HIPCHK(e, launch_gemm(a, EPI_PLAIN, 2, st));
+    }
+    return DR_OK;
+}
+
+int sampler_shape(int sampler, int B, int& NB, int& n_cond) {
+    switch (sampler) {
+        case DR_SAMPLER_DDPM_X0: NB = B; n_cond = B; return DR_OK;
+        case DR_SAMPLER_CFDG_DDPM_X0:
+        case DR_SAMPLER_INPAINTING_DDPM_X0: NB = 2 * B; n_cond = B; return DR_OK;
+        case DR_SAMPLER_GENERATION_DDPM_X0: NB = B; n_cond = 0; return DR_OK;
+    }
+    return DR_EINVAL;
+}
+
+int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int T, int t, float w, uint64_t seed,
+             int first_sample, hipStream_t st) {
+    int NB, n_cond;
+    if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
+    int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st);
+    if (rc) return rc;
+    UpdateArgs u{};
+    u.x = x; u.x0c = e->x0buf; u.x0u = (NB == 2 * B) ? e->x0buf + (size_t)B * T * 88 : nullptr;
+    u.noise = noise; u.coef = e->d_coef + (size_t)t * 5; u.t = t;
+    u.n = (long)B * T * 88; u.per_sample = (long)T * 88;
+    u.w = w; u.onepw = (float)(1.0 + (double)w);
+    u.seed = seed; u.first_sample = first_sample;
+    HIPCHK(e, launch_update(u, st));
+    return DR_OK;
+}
+
+int check_ready(dr_engine* e, int sampler, int B, int T) {
+    if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
+    if (sampler != DR_SAMPLER_GENERATION_DDPM_X0 && (e->fe_B != B || e->fe_T != T))
+        return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
+                    e->fe_B, e->fe_T, B, T);
+    return DR_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int dr_abi_version(void) { return DR_ABI_VERSION; }
+
+const char* dr_last_error(const dr_engine* e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int dr_create(dr_engine** out, const dr_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, DR_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != DR_ABI_VERSION)
+        return fail(nullptr, DR_EINVAL, "ABI version mismatch: header %d, library %d", cfg->abi_version, DR_ABI_VERSION);
+    if (cfg->residual_channels <= 0 || cfg->residual_channels % 4 || cfg->residual_layers <= 0 ||
+        cfg->kernel_size <= 0 || cfg->kernel_size % 2 == 0 || cfg->n_mels <= 0 || cfg->timesteps <= 0 ||
+        cfg->n_fft <= 0 || cfg->n_fft % 32 || cfg->hop_length <= 0 || cfg->hop_length % 4 ||
+        cfg->dilation_base <= 0 || cfg->dilation_bound <= 0)
+        return fail(nullptr, DR_EINVAL, "unsupported configuration");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, DR_EHIP, "no HIP device available: the engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DR_EINVAL, "device %d out of range", cfg->device);
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DR_EHIP, "hipSetDevice failed");
+    {
+        hipError_t ie = init_kernels();
+        if (ie != hipSuccess) return fail(nullptr, DR_EHIP, "kernel init failed: %s", hipGetErrorString(ie));
+    }
+    dr_engine* e = new dr_engine();
+    e->cfg = *cfg;
+    e->C = cfg->residual_channels;
+    e->Cp = round_up(e->C, 64);
+    e->L = cfg->residual_layers;
+    e->K = cfg->kernel_size;
+    e->S = cfg->timesteps;
+    e->NM = cfg->n_mels;
+    e->n_bins = cfg->n_fft / 2 + 1;
+    e->bins_p = round_up(e->n_bins, 64);
+    int maxdil = 1;
+    for (int i = 0; i < e->L; ++i) {
+        int d = 1;
+        for (int q = 0; q < i % cfg->dilation_bound; ++q) d *= cfg->dilation_base;
+        maxdil = std::max(maxdil, d);
+    }
+    if (64 + (e->K - 1) * maxdil > 256) {
+        delete e;
+        return fail(nullptr, DR_EINVAL, "receptive halo (k-1)*dil = %d too large for the LDS tile", (e->K - 1) * maxdil);
+    }
+    *out = e;
+    return DR_OK;
+}
+
+void dr_destroy(dr_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (void* p : e->owned) (void)hipFree(p);
+    float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->g, e->skip, e->tmp, e->x0buf, e->cond,
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm};
+    for (float* p : bufs) if (p) (void)hipFree(p);
+    delete e;
+}
+
+int dr_set_param(dr_engine* e, const char* name, const float* host_data, size_t numel) {
+    if (!e || !name || !host_data) return fail(e, DR_EINVAL, "null argument");
+    const size_t want = expected_numel(e, name);
+    if (want == 0) return fail(e, DR_ENAME, "unknown parameter '%s'", name);
+    if (want != numel) return fail(e, DR_ENAME, "parameter '%s': expected %zu elements, got %zu", name, want, numel);
+    e->params[name].assign(host_data, host_data + numel);
+    e->committed = false;
+    return DR_OK;
+}
+
+int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_coef) {
+    if (!e || !host_embedding || !host_coef) return fail(e, DR_EINVAL, "null argument");
+    e->h_emb.assign(host_embedding, host_embedding + (size_t)e->S * 128);
+    e->h_coef.assign(host_coef, host_coef + (size_t)e->S * 5);
+    e->committed = false;
+    return DR_OK;
+}
+
+int dr_commit(dr_engine* e, void* stream) {
+    if (!e) return DR_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (e->h_emb.empty() || e->h_coef.empty()) return fail(e, DR_ESTATE, "dr_set_tables has not been called");
+    const int C = e->C, Cp = e->Cp, L = e->L, K = e->K, NM = e->NM, S = e->S;
+    // all parameters present?
+    {
+        std::vector<std::string> names = {"input_projection.weight", "input_projection.bias",
+                                          "diffusion_embedding.projection1.weight", "diffusion_embedding.projection1.bias",
+                                          "diffusion_embedding.projection2.weight", "diffusion_embedding.projection2.bias",
+                                          "skip_projection.weight", "skip_projection.bias",
+                                          "output_projection.weight", "output_projection.bias"};
+        for (int l = 0; l < L; ++l)
+            for (const char* r : {"dilated_conv.weight", "dilated_conv.bias", "diffusion_projection.weight",
+                                  "diffusion_projection.bias", "conditioner_projection.weight",
+                                  "conditioner_projection.bias", "output_projection.weight", "output_projection.bias"})
+                names.push_back("residual_layers." + std::to_string(l) + "." + r);
+        for (auto& n : names)
+            if (!find_param(e, n)) return fail(e, DR_ESTATE, "parameter '%s' was never set", n.c_str());
+    }
+    for (void* p : e->owned) (void)hipFree(p);
+    e->owned.clear();
+    e->layers.assign(L, LayerW{});
+    int rc;
+    auto P = [&](const std::string& n) -> const std::vector<float>& { return *find_param(e, n); };
+
+    // ---- network weights --------------------------------------------------------------------
+    {   // input projection (C,88,1): natural rows
+        const auto& W = P("input_projection.weight");
+        const auto& Bv = P("input_projection.bias");
+        const int MT = (Cp + 127) / 128;
+        auto pk = pack_weights(MT, 3, 1, [&](int r, int ch, int) { return (r < C && ch < 88) ? W[(size_t)r * 88 + ch] : 0.f; });
+        std::vector<float> bb(MT * 128, 0.f);
+        for (int r = 0; r < C; ++r) bb[r] = Bv[r];
+        if ((rc = upload(e, pk, &e->in_w)) || (rc = upload(e, bb, &e->in_b))) return rc;
+    }
+    for (int l = 0; l < L; ++l) {
+        LayerW& lw = e->layers[l];
+        lw.dil = 1;
+        for (int q = 0; q < l % e->cfg.dilation_bound; ++q) lw.dil *= e->cfg.dilation_base;
+        const std::string pre = "residual_layers." + std::to_string(l) + ".";
+        const auto& Wd = P(pre + "dilated_conv.weight");
+        const auto& Bd = P(pre + "dilated_conv.bias");
+        const auto& Wc = P(pre + "conditioner_projection.weight");
+        const auto& Bc = P(pre + "conditioner_projection.bias");
+        const auto& Wo = P(pre + "output_projection.weight");
+        const auto& Bo = P(pre + "output_projection.bias");
+        const int MTc = Cp / 64;   // 2*Cp rows
+        auto pconv = pack_weights(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
+            int mi, c; paired_row(pr, mi, c);
+            return (c < C && ch < C) ? Wd[((size_t)(mi * C + c) * C + ch) * K + j] : 0.f;
+        });
+        auto pcond = pack_weights(MTc, (NM + 31) / 32, 1, [&](int pr, int ch, int) {
+            int mi, c; paired_row(pr, mi, c);
+            return (c < C && ch < NM) ? Wc[(size_t)(mi * C + c) * NM + ch] : 0.f;
+        });
+        std::vector<float> bconv(MTc * 128, 0.f), bconv_u(MTc * 128, 0.f), bcond(MTc * 128, 0.f);
+        for (int pr = 0; pr < MTc * 128; ++pr) {
+            int mi, c; paired_row(pr, mi, c);
+            if (c >= C) continue;
+            const int o = mi * C + c;
+            double sw = 0.0;
+            for (int m = 0; m < NM; ++m) sw += (double)Wc[(size_t)o * NM + m];
+            const float cu = (float)((double)Bc[o] - sw);   // conditioner of spec == -1 (model/diffwave.py:660)
+            bconv[pr] = Bd[o];
+            bconv_u[pr] = Bd[o] + cu;
+            bcond[pr] = Bc[o];
+        }
+        // 1x1 output projection (2C,C,1): packed rows [0,Cp) residual, [Cp,2Cp) skip
+        auto pout = pack_weights(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
+            const int half = pr >= Cp, c = pr - half * Cp;
+            return (c < C && ch < C) ? Wo[(size_t)(half * C + c) * C + ch] : 0.f;
+        });
+        std::vector<float> bout(MTc * 128, 0.f);
+        for (int pr = 0; pr < 2 * Cp; ++pr) {
+            const int half = pr >= Cp, c = pr - half * Cp;
+            if (c < C) bout[pr] = Bo[half * C + c];
+        }
+        if ((rc = upload(e, pconv, &lw.conv_w)) || (rc = upload(e, bconv, &lw.conv_b)) ||
+            (rc = upload(e, bconv_u, &lw.conv_b_u)) || (rc = upload(e, pcond, &lw.cond_w)) ||
+            (rc = upload(e, bcond, &lw.cond_b)) || (rc = upload(e, pout, &lw.out_w)) ||
+            (rc = upload(e, bout, &lw.out_b)))
+            return rc;
+    }
+    {   // skip projection (C,C,1) and output projection (88,C,1): natural rows
+        const auto& Ws = P("skip_projection.weight");
+        const auto& Bs = P("skip_projection.bias");
+        const int MT = (Cp + 127) / 128;
+        auto pk = pack_weights(MT, Cp / 32, 1, [&](int r, int ch, int) { return (r < C && ch < C) ? Ws[(size_t)r * C + ch] : 0.f; });
+        std::vector<float> bb(MT * 128, 0.f);
+        for (int r = 0; r < C; ++r) bb[r] = Bs[r];
+        if ((rc = upload(e, pk, &e->skip_w)) || (rc = upload(e, bb, &e->skip_b))) return rc;
+        const auto& Wo = P("output_projection.weight");
+        const auto& Bo = P("output_projection.bias");
+        auto pk2 = pack_weights(1, Cp / 32, 1, [&](int r, int ch, int) { return (r < 88 && ch < C) ? Wo[(size_t)r * C + ch] : 0.f; });
+        std::vector<float> b2(128, 0.f);
+        for (int r = 0; r < 88; ++r) b2[r] = Bo[r];
+        if ((rc = upload(e, pk2, &e->outp_w)) || (rc = upload(e, b2, &e->outp_b))) return rc;
+    }
+    // ---- front-end constants: windowed DFT matrix and HTK mel filterbank -----------------------
+    {
+        const int N = e->cfg.n_fft, nb = e->n_bins, bp = e->bins_p;
+        std::vector<double> win(N);
+        double s2 = 0.0;
+        for (int k = 0; k < N; ++k) { win[k] = 0.5 - 0.5 * std::cos(2.0 * M_PI * k / N); s2 += win[k] * win[k]; }
+        const double norm = 1.0 / std::sqrt(s2);   // normalized=True: / sqrt(sum(window^2))
+        // cos/sin via an exact-phase table (k*bin mod N) to keep the twiddles accurate
+        std::vector<double> ct(N), sn(N);
+        for (int k = 0; k < N; ++k) { ct[k] = std::cos(2.0 * M_PI * k / N); sn[k] = std::sin(2.0 * M_PI * k / N); }
+        auto pk = pack_weights(bp / 64, N / 32, 1, [&](int pr, int k, int) {
+            int mi, bin; paired_row(pr, mi, bin);
+            if (bin >= nb) return 0.f;
+            const int ph = (int)(((long long)k * bin) % N);
+            return (float)(win[k] * norm * (mi == 0 ? ct[ph] : sn[ph]));
+        });
+        if ((rc = upload(e, pk, &e->dft_w))) return rc;
+        // torchaudio.functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, 'htk')
+        const double fmin = e->cfg.f_min, fmax = e->cfg.f_max;
+        auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
+        const double m_min = hz2mel(fmin), m_max = hz2mel(fmax);
+        std::vector<double> fpts(NM + 2);
+        for (int i = 0; i < NM + 2; ++i) {
+            const double m = m_min + (m_max - m_min) * i / (NM + 1);
+            fpts[i] = 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+        }
+        const double nyq = (double)(e->cfg.sample_rate / 2);
+        auto fbv = [&](int bin, int mel) {
+            const double f = nyq * bin / (nb - 1);
+            const double down = (f - fpts[mel]) / (fpts[mel + 1] - fpts[mel]);
+            const double up = (fpts[mel + 2] - f) / (fpts[mel + 2] - fpts[mel + 1]);
+            return std::max(0.0, std::min(down, up));
+        };
+        const int MTm = (NM + 127) / 128;
+        auto pm = pack_weights(MTm, bp / 32, 1, [&](int r, int ch, int) {
+            return (r < NM && ch < nb) ? (float)fbv(ch, r) : 0.f;
+        });
+        if ((rc = upload(e, pm, &e->mel_w))) return rc;
+    }
+    // ---- tables ------------------------------------------------------------------------------
+    if ((rc = dev_alloc(e, &e->d_coef, (size_t)S * 5))) return rc;
+    HIPCHK(e, hipMemcpy(e->d_coef, e->h_coef.data(), (size_t)S * 5 * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(e, &e->d_dtab, (size_t)S * L * Cp))) return rc;
+    {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
+        // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by
+        // the same GEMM kernel; result d_dtab[t][l][c].
+        std::vector<float> embP4((size_t)32 * S * 4);
+        for (int t = 0; t < S; ++t)
+            for (int c = 0; c < 128; ++c) embP4[((size_t)(c / 4) * S + t) * 4 + (c % 4)] = e->h_emb[(size_t)t * 128 + c];
+        float *d_emb = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+        float *a1 = nullptr, *a2 = nullptr;
+        if ((rc = upload(e, embP4, &d_emb))) return rc;
+        const auto& W1 = P("diffusion_embedding.projection1.weight");
+        const auto& W2 = P("diffusion_embedding.projection2.weight");
+        auto p1 = pack_weights(4, 4, 1, [&](int r, int ch, int) { return W1[(size_t)r * 128 + ch]; });
+        auto p2 = pack_weights(4, 16, 1, [&](int r, int ch, int) { return W2[(size_t)r * 512 + ch]; });
+        if ((rc = upload(e, p1, &w1)) || (rc = upload(e, P("diffusion_embedding.projection1.bias"), &b1)) ||
+            (rc = upload(e, p2, &w2)) || (rc = upload(e, P("diffusion_embedding.projection2.bias"), &b2)))
+            return rc;
+        if ((rc = dev_alloc(e, &a1, (size_t)512 * S)) || (rc = dev_alloc(e, &a2, (size_t)512 * S))) return rc;
+        GemmArgs g1 = p4_gemm(w1, b1, 4, d_emb, 32, 1, S);
+        p4_out(g1, a1, 128, S, 512);
+        HIPCHK(e, launch_gemm(g1, EPI_SILU, 2, st));
+        GemmArgs g2 = p4_gemm(w2, b2, 4, a1, 128, 1, S);
+        p4_out(g2, a2, 128, S, 512);
+        HIPCHK(e, launch_gemm(g2, EPI_SILU, 2, st));
+        const int MT = (Cp + 127) / 128;
+        for (int l = 0; l < L; ++l) {
+            const std::string pre = "residual_layers." + std::to_string(l) + ".";
+            const auto& Wd = P(pre + "diffusion_projection.weight");
+            const auto& Bd = P(pre + "diffusion_projection.bias");
+            auto pd = pack_weights(MT, 16, 1, [&](int r, int ch, int) { return r < C ? Wd[(size_t)r * 512 + ch] : 0.f; });
+            std::vector<float> bb(MT * 128, 0.f);
+            for (int r = 0; r < C; ++r) bb[r] = Bd[r];
+            float *wd = nullptr, *bd = nullptr;
+            if ((rc = upload(e, pd, &wd)) || (rc = upload(e, bb, &bd))) return rc;
+            GemmArgs g3 = p4_gemm(wd, bd, MT, a2, 128, 1, S);
+            g3.Y = e->d_dtab + (size_t)l * Cp; g3.y_bs = 0; g3.y_ps = 4; g3.y_fs = (long)L * Cp; g3.y_rows = Cp;
+            HIPCHK(e, launch_gemm(g3, EPI_PLAIN, 2, st));
+        }
+        HIPCHK(e, hipStreamSynchronize(st));
+        (void)hipFree(a1);
+        (void)hipFree(a2);
+    }
+    e->committed = true;
+    e->fe_B = e->fe_T = 0;
+    return DR_OK;
+}
+
+int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int mask_t0, int mask_t1, int mask_f0,
+                int mask_f1, float* d_spec_out, void* stream) {
+    if (!e || !d_wav) return fail(e, DR_EINVAL, "null argument");
+    if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = e->cfg.n_fft, hop = e->cfg.hop_length, pad = N / 2;
+    if (B <= 0 || L <= pad || T_roll <= 0) return fail(e, DR_EINVAL, "bad front-end shape B=%d L=%d T=%d", B, L, T_roll);
+    const int TF = L / hop + 1;
+    const int T = std::min(T_roll, TF);
+    const int Lp = (L + 2 * pad + 3) & ~3;
+    const int Cp = e->Cp, NM = e->NM, bp = e->bins_p;
+    const int mel_planes = (NM + 3) / 4;
+    int rc;
+    HIPCHK(e, hipStreamSynchronize(st));   // buffers below may be reallocated
+    if ((size_t)B * Lp > e->fe_cap_wav) { if ((rc = dev_alloc(e, &e->wav_pad, (size_t)B * Lp))) return rc; e->fe_cap_wav = (size_t)B * Lp; }
+    if ((size_t)B * bp * TF > e->fe_cap_pow) { if ((rc = dev_alloc(e, &e->power, (size_t)B * bp * TF))) return rc; e->fe_cap_pow = (size_t)B * bp * TF; }
+    if ((size_t)B * mel_planes * 4 * TF > e->fe_cap_log) { if ((rc = dev_alloc(e, &e->logmel, (size_t)B * mel_planes * 4 * TF))) return rc; e->fe_cap_log = (size_t)B * mel_planes * 4 * TF; }
+    if ((size_t)B * mel_planes * 4 * T > e->fe_cap_spec) { if ((rc = dev_alloc(e, &e->specP4, (size_t)B * mel_planes * 4 * T))) return rc; e->fe_cap_spec = (size_t)B * mel_planes * 4 * T; }
+    if ((size_t)B * 2 > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, (size_t)B * 2))) return rc; e->fe_cap_mm = (size_t)B * 2; }
+    const size_t cond_need = (size_t)e->L * B * 2 * Cp * T;
+    if (cond_need > e->cond_cap) { if ((rc = dev_alloc(e, &e->cond, cond_need))) return rc; e->cond_cap = cond_need; }
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }   // cond layout may change
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    e->gkey = GraphKey{};
+
+    // 1. center / reflect padding
+    HIPCHK(e, launch_reflect_pad(d_wav, e->wav_pad, B, L, pad, st));
+    // 2. STFT power = |windowed DFT|^2: frames are read straight out of the padded waveform
+    //    (plane stride 4 samples, frame stride hop) - no im2col copy.
+    {
+        GemmArgs a{};
+        a.Wp = e->dft_w; a.MT = bp / 64;
+        a.X = e->wav_pad; a.x_bs = Lp; a.x_ps = 4; a.x_fs = hop; a.x_planes = N / 4; a.kchunks = N / 32;
+        a.NB = B; a.T = TF; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+        p4_out(a, e->power, bp / 4, TF, bp);
+        HIPCHK(e, launch_gemm(a, EPI_POWER, 2, st));
+    }
+    // 3. mel filterbank + log(. + 1e-6)   (model/diffwave.py:644)
+    {
+        GemmArgs a = p4_gemm(e->mel_w, nullptr, (NM + 127) / 128, e->power, bp / 4, B, TF);
+        p4_out(a, e->logmel, mel_planes, TF, mel_planes * 4);
+        HIPCHK(e, launch_gemm(a, EPI_LOG, 2, st));
+    }
+    // 4. imagewise min-max over the untrimmed TF frames, mask, trim
+    HIPCHK(e, launch_minmax(e->logmel, e->mm, B, mel_planes, TF, NM, st));
+    HIPCHK(e, launch_normalize(e->logmel, e->mm, e->specP4, d_spec_out, B, mel_planes, mel_planes, TF, T, NM,
+                               mask_t0, mask_t1, mask_f0, mask_f1, st));
+    // 5. hoisted conditioner projections, one (B, 2C, T) tensor per layer (model/diffwave.py:143)
+    for (int l = 0; l < e->L; ++l) {
+        const LayerW& w = e->layers[l];
+        GemmArgs a = p4_gemm(w.cond_w, w.cond_b, Cp / 64, e->specP4, mel_planes, B, T);
+        p4_out(a, e->cond + (size_t)l * B * 2 * Cp * T, 2 * Cp / 4, T, 2 * Cp);
+        HIPCHK(e, launch_gemm(a, EPI_PLAIN, 2, st));
+    }
+    e->fe_B = B;
+    e->fe_T = T;
+    return DR_OK;
+}
+
+int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond, float* d_x0_out, void* stream) {
+    if (!e || !d_x || !d_x0_out) return fail(e, DR_EINVAL, "null argument");
+    const int sampler = cond == DR_COND_UNCOND ? DR_SAMPLER_GENERATION_DDPM_X0 : DR_SAMPLER_DDPM_X0;
+    int rc = check_ready(e, sampler, B, T);
+    if (rc) return rc;
+    if (t < 0 || t >= e->S) return fail(e, DR_EINVAL, "step %d out of range", t);
+    if ((rc = ensure_workspace(e, B, T))) return rc;
+    return run_network(e, d_x, 0, B, cond == DR_COND_UNCOND ? 0 : B, T, t, d_x0_out, (hipStream_t)stream);
+}
+
+int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, int t, float w, uint64_t seed,
+            int first_sample, void* stream) {
+    if (!e || !d_x) return fail(e, DR_EINVAL, "null argument");
+    int rc = check_ready(e, sampler, B, T);
+    if (rc) return rc;
+    if (t < 0 || t >= e->S) return fail(e, DR_EINVAL, "step %d out of range", t);
+    int NB, n_cond;
+    if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
+    if ((rc = ensure_workspace(e, NB, T))) return rc;
+    return run_step(e, sampler, d_x, d_noise, B, T, t, w, seed, first_sample, (hipStream_t)stream);
+}
+
+int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, float w, uint64_t seed,
+              int first_sample, int use_graph, void* stream) {
+    if (!e || !d_x) return fail(e, DR_EINVAL, "null argument");
+    int rc = check_ready(e, sampler, B, T);
+    if (rc) return rc;
+    int NB, n_cond;
+    if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
+    if ((rc = ensure_workspace(e, NB, T))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per = (size_t)B * T * 88;
+    auto chain = [&]() -> int {
+        for (int t = e->S - 1; t >= 0; --t) {
+            // row t of the injected noise is the z of step t; t == 0 draws none (task/diffusion.py:957-960)
+            const float* z = d_noise ? d_noise + (size_t)t * per : nullptr;
+            int r = run_step(e, sampler, d_x, z, B, T, t, w, seed, first_sample, st);
+            if (r) return r;
+        }
+        return DR_OK;
+    };
+    if (!use_graph || e->prof) return chain();
+
+    GraphKey key;
+    key.sampler = sampler; key.B = B; key.T = T; key.first_sample = first_sample; key.x = d_x; key.noise = d_noise;
+    key.w = w; key.seed = seed;
+    if (!e->gexec || !(key == e->gkey)) {
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        if (!e->cap_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+        hipStream_t user = st;
+        st = e->cap_stream;   // chain() launches on `st`
+        HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = chain();
+        hipGraph_t gr = nullptr;
+        hipError_t ce = hipStreamEndCapture(st, &gr);
+        st = user;
+        if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+        if (ce != hipSuccess) return fail(e, DR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        e->graph = gr;
+        HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+        e->gkey = key;
+    }
+    HIPCHK(e, hipGraphLaunch(e->gexec, st));
+    return DR_OK;
+}
+
+int dr_profile_enable(dr_engine* e, int on) {
+    if (!e) return DR_EINVAL;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    e->prof = on != 0;
+    if (e->prof && e->prof_events.empty()) {
+        const size_t n = (size_t)e->S * e->L;
+        e->prof_events.resize(n);
+        for (auto& p : e->prof_events) { HIPCHK(e, hipEventCreate(&p.first)); HIPCHK(e, hipEventCreate(&p.second)); }
+    }
+    e->prof_used = 0;
+    return DR_OK;
+}
+
+int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset) {
+    if (!e) return DR_EINVAL;
+    HIPCHK(e, hipDeviceSynchronize());
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, e->prof_events[i].first, e->prof_events[i].second));
+        e->prof_ms += ms;
+        e->prof_launches += 1;
+    }
+    e->prof_used = 0;
+    if (launches) *launches = e->prof_launches;
+    if (total_ms) *total_ms = e->prof_ms;
+    if (reset) { e->prof_launches = 0; e->prof_ms = 0.0; }
+    return DR_OK;
+}
+
+int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, void* stream) {
+    if (!e) return DR_EINVAL;
+    if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    if (layer < 0 || layer >= e->L || t < 0 || t >= e->S || n_cond < 0 || n_cond > NB)
+        return fail(e, DR_EINVAL, "bad argument");
+    if (n_cond > 0 && (e->fe_B < n_cond || e->fe_T != T)) return fail(e, DR_ESTATE, "dr_frontend needed for n_cond > 0");
+    int rc = ensure_workspace(e, NB, T);
+    if (rc) return rc;
+    const int Cp = e->Cp, P = Cp / 4;
+    const LayerW& w = e->layers[layer];
+    GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->h, P, NB, T);
+    a.bias2 = w.conv_b_u;
+    a.dvec = e->d_dtab + ((size_t)t * e->L + layer) * Cp;
+    a.taps = e->K; a.dil = w.dil;
+    a.cond = e->cond ? e->cond + (size_t)layer * e->fe_B * 2 * Cp * T : nullptr;
+    a.c_bs = (long)2 * Cp * T;
+    a.n_cond = n_cond;
+    p4_out(a, e->g, P, T, Cp);
+    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(e->K, w.dil), (hipStream_t)stream));
+    return DR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Internal launch interface between engine.hip (host logic, C-ABI) and kernels.hip (gfx950 kernels).
+// Not part of the public ABI (that is include/diffroll_amd.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dr {
+
+// ---------------------------------------------------------------------------------------------
+// Data layouts in HBM
+//
+//  "P4" activation layout: a (batch, channels, frames) tensor is stored as
+//        [batch][plane = channel/4][frame][4]        (fp32; one float4 per (plane, frame))
+//  so that (a) a wavefront's 64 lanes reading consecutive frames of a plane move 1 KiB
+//  contiguously, (b) the float4 is exactly the 4 consecutive K-values an MFMA lane consumes
+//  over 4 consecutive v_mfma_f32_32x32x2_f32 issues, and (c) the MFMA C/D fragment (4 consecutive
+//  rows per lane per register quad) is written back as one float4 with no shuffles.
+//  The roll (B, T, 88) is addressed with the same (batch, plane, frame) strides
+//  (plane stride 4, frame stride 88), so no transposed copy is ever made.
+//
+//  Packed weights: for a GEMM  Y[M][N] = W[M][K] X[K][N]  with K = taps x Cin,
+//        Wp[mtile][kchunk][tap][g = 0..3][hi = 0..1][row = 0..127][4]
+//  = W[orig_row(mtile,row)][channel = kchunk*32 + g*8 + hi*4 + i][tap]; one (mtile,kchunk,tap)
+//  slab is 16 KiB, contiguous, and is the exact LDS image the kernel reads (linear copy).
+// ---------------------------------------------------------------------------------------------
+
+enum Epilogue : int {
+    EPI_PLAIN = 0,     // y = alpha*acc + bias
+    EPI_RELU = 1,      // y = relu(alpha*acc + bias)
+    EPI_SILU = 2,      // y = silu(acc + bias)
+    EPI_GATE = 3,      // rows paired (gate, filter): y = sigmoid(a0 + c0) * tanh(a1 + c1)
+    EPI_RES_SKIP = 4,  // first half of M: h = (h + acc + b)/sqrt(2) in place; second half: skip (+)= acc + b
+    EPI_POWER = 5,     // rows paired (cos, sin): y = a0^2 + a1^2
+    EPI_LOG = 6        // y = log(acc + 1e-6)
+};
+
+struct GemmArgs {
+    // A operand
+    const float* Wp;      // packed weights
+    const float* bias;    // [MT*128] in packed-row order (may be null)
+    const float* bias2;   // EPI_GATE: bias for samples >= n_cond (unconditional: conv bias + cond const)
+    // B operand
+    const float* X;
+    long x_bs, x_ps, x_fs;   // batch / plane / frame strides in floats
+    int x_planes;            // valid planes (Cin/4); planes beyond read as zero
+    int x_bmod;              // sample index is taken modulo this (0 = no modulo)
+    const float* dvec;       // [Cin] added to every valid in-range frame before zero padding (may be null)
+    int NB, T;               // samples, frames per sample
+    int taps, dil;           // conv taps (odd) and dilation; halo = (taps-1)/2*dil
+    int kchunks;             // ceil(Cin/32)
+    int MT;                  // M tiles of 128 packed rows
+    // output
+    float* Y;
+    long y_bs, y_ps, y_fs;
+    int y_rows;              // valid output rows (quads starting at >= y_rows are not written)
+    // epilogue extras
+    const float* cond;       // EPI_GATE: [n_cond][MT*32 planes][T][4] in packed-row order
+    long c_bs;
+    int n_cond;
+    float* skip;             // EPI_RES_SKIP: P4 [NB][MT/2*32 planes][T][4]
+    long s_bs;
+    int skip_init;           // 1: skip = value, 0: skip += value
+    float alpha;
+};
+
+// NI = N sub-tiles of 32 frames per wave: block tile = 128 rows x (64*NI) frames, 256 threads.
+hipError_t init_kernels();
+hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s);
+size_t gemm_lds_bytes(int NI, int taps, int dil);
+int gemm_max_halo(int NI);
+
+struct UpdateArgs {
+    float* x;              // (B, T, 88) in/out
+    const float* x0c;      // (B, T, 88) conditional (or the only) prediction
+    const float* x0u;      // unconditional prediction or null
+    const float* noise;    // (B, T, 88) or null -> philox
+    const float* coef;     // device pointer to this step's 5 coefficients
+    int t;                 // step index
+    long n;                // B*T*88
+    long per_sample;       // T*88
+    float w, onepw;
+    uint64_t seed;
+    int first_sample;
+};
+hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
+
+hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pad, hipStream_t s);
+// per-sample min/max of logmel P4 [B][planes][TF][4] over rows < n_rows -> mm[B][2]
+hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
+// normalise, mask, trim -> spec P4 [B][planes_out][T][4] (rows >= n_rows zero) and optional plain (B, n_rows, T)
+hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4, float* spec_plain,
+                            int B, int planes_in, int planes_out, int TF, int T, int n_rows,
+                            int mt0, int mt1, int mf0, int mf1, hipStream_t s);
+hipError_t launch_fill(float* p, float v, long n, hipStream_t s);
+
+}  // namespace dr

@@ -1,0 +1,510 @@
+// gfx950 (MI355X, CDNA4) kernels of the DiffRoll sampling engine.
+//
+// One templated implicit-GEMM kernel on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 carries every contraction of the path:
+//   * dilated Conv1d (k taps) + conditioner add + sigmoid*tanh gate   (model/diffwave.py:139-147)
+//   * 1x1 output projection + residual/skip update                     (model/diffwave.py:149-151)
+//   * input / skip / output projections of the net                     (model/diffwave.py:667-668, 683-685)
+//   * conditioner projections, step-embedding MLP                      (hoisted; :126,128,65-74)
+//   * the STFT as a windowed-DFT GEMM and the mel filterbank GEMM      (torchaudio MelSpectrogram)
+// plus small HBM-bound kernels: posterior update + classifier-free combine + Philox noise
+// (task/diffusion.py:953-967), reflect padding, per-sample min/max + normalise/mask/trim
+// (model/utils.py:21-32, model/diffwave.py:644-662).
+//
+// Written for wave64 / 4 waves per workgroup; no other target is supported.
+#include "kernels.h"
+
+namespace dr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DR_DEVINL __device__ __forceinline__
+
+DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM kernel.
+//   block = 256 threads = 4 waves as 2 (M) x 2 (N); block tile 128 packed rows x BN = 64*NI frames
+//   wave tile 64 rows (2 MFMA row-tiles: for the paired epilogues the gate/cos tile and the
+//   filter/sin tile of the SAME 32 channels, so pairing is register-local) x 32*NI frames.
+//   K loop: for kchunk (32 input channels; X tile with halo staged once) for tap (W slab 16 KiB):
+//   64*NI MFMAs per wave per step, one __syncthreads per step, register-staged double buffering.
+//   LDS: X tile [2][8 planes][FW = BN + 2*halo][float4]  +  W slab [2][4][2][128][float4].
+//   All fragment reads are conflict-free ds_read_b128 (lane-contiguous 16 B).
+// ---------------------------------------------------------------------------------------------
+template <int NI, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = 64 * NI;
+    constexpr int WN = 32 * NI;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, hi = lane >> 5;
+
+    const int halo = ((a.taps - 1) >> 1) * a.dil;
+    const int FW = BN + 2 * halo;
+    float4* Xs = reinterpret_cast<float4*>(smem);   // [2][8][FW]
+    float4* Ws = Xs + 2 * 8 * FW;                   // [2][1024]
+
+    // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
+    // one 128-row weight panel, which then stays resident in that XCD's private L2.
+    const int mt = blockIdx.x % a.MT;
+    const int nt = blockIdx.x / a.MT;
+    const int tps = (a.T + BN - 1) / BN;
+    const int b = nt / tps;
+    const int t0 = (nt % tps) * BN;
+    const int bx = a.x_bmod ? (b % a.x_bmod) : b;
+    const float* Xg = a.X + (long)bx * a.x_bs;
+    const int NS = a.kchunks * a.taps;
+    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024;
+
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    const int tx = t0 - halo + tid;                 // frame this thread stages
+    const bool xin = (tid < FW) && (tx >= 0) && (tx < a.T);
+    const float* Xt = Xg + (long)tx * a.x_fs;
+
+    float4 xr[8];
+    float4 wreg[4];
+
+    auto load_x = [&](int kc) {
+#pragma unroll
+        for (int pl = 0; pl < 8; ++pl) {
+            const int plane = kc * 8 + pl;
+            float4 v = f4zero();
+            if (xin && plane < a.x_planes) {
+                v = *reinterpret_cast<const float4*>(Xt + (long)plane * a.x_ps);
+                if (a.dvec) {
+                    const float4 d = *reinterpret_cast<const float4*>(a.dvec + plane * 4);
+                    v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+                }
+            }
+            xr[pl] = v;
+        }
+    };
+    auto store_x = [&](int buf) {
+        if (tid < FW) {
+#pragma unroll
+            for (int pl = 0; pl < 8; ++pl) Xs[(buf * 8 + pl) * FW + tid] = xr[pl];
+        }
+    };
+    auto load_w = [&](int s) {
+        const float4* src = Wg + (long)s * 1024 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wreg[i] = src[i * 256];
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ws[buf * 1024 + i * 256 + tid] = wreg[i];
+    };
+
+    load_x(0);
+    load_w(0);
+    store_x(0);
+    store_w(0);
+    __syncthreads();
+
+    const int cen = (a.taps - 1) >> 1;
+    int kc = 0, j = 0;
+    for (int s = 0; s < NS; ++s) {
+        const bool more = (s + 1 < NS);
+        const bool newx = more && (j == a.taps - 1);
+        if (more) load_w(s + 1);
+        if (newx) load_x(kc + 1);
+
+        const float4* Xb = Xs + (kc & 1) * 8 * FW + hi * FW + halo + (j - cen) * a.dil + wc * WN + r;
+        const float4* Wb = Ws + (s & 1) * 1024 + hi * 128 + wr * 64 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 af[2], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = Wb[g * 256 + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bf[ni] = Xb[g * 2 * FW + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+
+        if (more) store_w((s + 1) & 1);
+        if (newx) store_x((kc + 1) & 1);
+        __syncthreads();
+        if (++j == a.taps) { j = 0; ++kc; }
+    }
+
+    // ----------------------------------------------------------------------------------------
+    // epilogue.  C/D fragment of 32x32: column = lane&31 (frame), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
+    // ----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int t = t0 + wc * WN + ni * 32 + r;
+        if (t >= a.T) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rq = 8 * q + 4 * hi;   // row offset inside a 32-row MFMA tile
+            if constexpr (EPI == EPI_GATE || EPI == EPI_POWER) {
+                const int p0 = mt * 128 + wr * 64 + rq;   // packed row of the gate / cos quad
+                const int p1 = p0 + 32;                   // packed row of the filter / sin quad
+                const int c0 = mt * 64 + wr * 32 + rq;    // output channel of the quad
+                if (c0 >= a.y_rows) continue;
+                float v0[4], v1[4], o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[1][ni][4 * q + e]; }
+                if constexpr (EPI == EPI_GATE) {
+                    float4 a0, a1;
+                    if (b < a.n_cond) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + p0);
+                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + p1);
+                        const float* cb = a.cond + (long)b * a.c_bs + (long)t * 4;
+                        const float4 c0v = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
+                        const float4 c1v = *reinterpret_cast<const float4*>(cb + (long)(p1 >> 2) * a.T * 4);
+                        a0 = make_float4(b0.x + c0v.x, b0.y + c0v.y, b0.z + c0v.z, b0.w + c0v.w);
+                        a1 = make_float4(b1.x + c1v.x, b1.y + c1v.y, b1.z + c1v.z, b1.w + c1v.w);
+                    } else {
+                        a0 = *reinterpret_cast<const float4*>(a.bias2 + p0);
+                        a1 = *reinterpret_cast<const float4*>(a.bias2 + p1);
+                    }
+                    const float ad0[4] = {a0.x, a0.y, a0.z, a0.w};
+                    const float ad1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v0[e] + ad0[e]) * tanhf(v1[e] + ad1[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
+                }
+                float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int p0 = mt * 128 + wr * 64 + mi * 32 + rq;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
+                    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + p0);
+                        bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
+                    }
+                    if constexpr (EPI == EPI_RES_SKIP) {
+                        // packed rows [0, y_rows) are the residual half, [y_rows, 2*y_rows) the skip half
+                        // (y_rows is a multiple of 64, so the branch is wave-uniform)
+                        if (p0 < a.y_rows) {   // h = (h + (acc + b)) / sqrt(2), in place
+                            float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                            const float4 h4 = *reinterpret_cast<const float4*>(dst);
+                            const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (hh[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        } else {           // skip rows
+                            const int ps = (p0 - a.y_rows) >> 2;
+                            float* dst = a.skip + (long)b * a.s_bs + ((long)ps * a.T + t) * 4;
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = v[e] + bb[e];
+                            if (!a.skip_init) {
+                                const float4 s4 = *reinterpret_cast<const float4*>(dst);
+                                o[0] += s4.x; o[1] += s4.y; o[2] += s4.z; o[3] += s4.w;
+                            }
+                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                    } else {
+                        if (p0 >= a.y_rows) continue;
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (EPI == EPI_PLAIN) o[e] = a.alpha * v[e] + bb[e];
+                            else if constexpr (EPI == EPI_RELU) o[e] = fmaxf(a.alpha * v[e] + bb[e], 0.f);
+                            else if constexpr (EPI == EPI_SILU) { const float z = v[e] + bb[e]; o[e] = z * sigmoidf_(z); }
+                            else o[e] = logf(v[e] + 1e-6f);
+                        }
+                        float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+size_t gemm_lds_bytes(int NI, int taps, int dil) {
+    const int halo = ((taps - 1) / 2) * dil;
+    const int FW = 64 * NI + 2 * halo;
+    return (size_t)2 * 8 * FW * 16 + (size_t)2 * 16384;
+}
+int gemm_max_halo(int NI) { return (256 - 64 * NI) / 2; }
+
+template <int NI, int EPI>
+static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    const int BN = 64 * NI;
+    const int tps = (a.T + BN - 1) / BN;
+    const size_t lds = gemm_lds_bytes(NI, a.taps, a.dil);
+    const dim3 grid((unsigned)(a.MT * a.NB * tps));
+    hipLaunchKernelGGL((gemm_kernel<NI, EPI>), grid, dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int NI, int EPI>
+static hipError_t init_gemm_t() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NI, EPI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int NI>
+static hipError_t init_gemm_ni() {
+    hipError_t e;
+    if ((e = init_gemm_t<NI, EPI_PLAIN>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, EPI_RELU>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, EPI_SILU>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, EPI_GATE>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, EPI_RES_SKIP>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, EPI_POWER>()) != hipSuccess) return e;
+    return init_gemm_t<NI, EPI_LOG>();
+}
+// allow > 64 KiB of dynamic LDS for every instantiation; call once per process before any launch
+// (and never inside a stream capture)
+hipError_t init_kernels() {
+    hipError_t e = init_gemm_ni<1>();
+    if (e != hipSuccess) return e;
+    return init_gemm_ni<2>();
+}
+
+template <int NI>
+static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_PLAIN: return launch_gemm_t<NI, EPI_PLAIN>(a, s);
+        case EPI_RELU: return launch_gemm_t<NI, EPI_RELU>(a, s);
+        case EPI_SILU: return launch_gemm_t<NI, EPI_SILU>(a, s);
+        case EPI_GATE: return launch_gemm_t<NI, EPI_GATE>(a, s);
+        case EPI_RES_SKIP: return launch_gemm_t<NI, EPI_RES_SKIP>(a, s);
+        case EPI_POWER: return launch_gemm_t<NI, EPI_POWER>(a, s);
+        case EPI_LOG: return launch_gemm_t<NI, EPI_LOG>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s) {
+    const int halo = ((a.taps - 1) / 2) * a.dil;
+    if (64 * NI + 2 * halo > 256) return hipErrorInvalidValue;
+    switch (NI) {
+        case 1: return launch_gemm_ni<1>(a, epi, s);
+        case 2: return launch_gemm_ni<2>(a, epi, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: z ~ N(0,1), keyed by (seed, global sample, step, element/4) so the
+// noise of a sample does not depend on how the batch is sharded over GPUs.
+// ---------------------------------------------------------------------------------------------
+DR_DEVINL void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                             uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+DR_DEVINL void box_muller(uint32_t u0, uint32_t u1, float& z0, float& z1) {
+    const float a = ((float)(u0 >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0, 1]
+    const float bb = (float)(u1 >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(a));
+    float sn, cs;
+    sincosf(6.283185307179586f * bb, &sn, &cs);
+    z0 = rad * cs;
+    z1 = rad * sn;
+}
+
+// Classifier-free combine + x0-prediction posterior update, one float4 per thread.
+// Same operation order as task/diffusion.py:953 and :957-967; contraction off so that no FMA is
+// formed where the reference rounds twice.
+__global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
+#pragma clang fp contract(off)
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= a.n) return;
+    const float4 xc = reinterpret_cast<const float4*>(a.x0c)[i4];
+    float x0[4] = {xc.x, xc.y, xc.z, xc.w};
+    if (a.x0u) {
+        const float4 xu = reinterpret_cast<const float4*>(a.x0u)[i4];
+        const float u[4] = {xu.x, xu.y, xu.z, xu.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x0[e] = a.onepw * x0[e] - a.w * u[e];
+    }
+    const float c_prev = a.coef[0], c_dir = a.coef[1], sac_t = a.coef[2], s1m_t = a.coef[3], sigma = a.coef[4];
+    float o[4];
+    if (a.t == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = x0[e] / sac_t;
+    } else {
+        const float4 xv = reinterpret_cast<const float4*>(a.x)[i4];
+        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
+        float z[4];
+        if (a.noise) {
+            const float4 zv = reinterpret_cast<const float4*>(a.noise)[i4];
+            z[0] = zv.x; z[1] = zv.y; z[2] = zv.z; z[3] = zv.w;
+        } else {
+            const long e0 = i4 * 4;
+            const long smp = e0 / a.per_sample;
+            const long within = (e0 - smp * a.per_sample) >> 2;
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)within, (uint32_t)(within >> 32), (uint32_t)a.t,
+                          (uint32_t)(a.first_sample + smp), (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+            box_muller(rnd[0], rnd[1], z[0], z[1]);
+            box_muller(rnd[2], rnd[3], z[2], z[3]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t1 = c_prev * x0[e];
+            const float t2 = (c_dir * (x[e] - sac_t * x0[e])) / s1m_t;
+            const float t3 = sigma * z[e];
+            o[e] = (t1 + t2) + t3;
+        }
+    }
+    reinterpret_cast<float4*>(a.x)[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_update(const UpdateArgs& a, hipStream_t s) {
+    const long n4 = a.n / 4;
+    hipLaunchKernelGGL(update_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// front-end helpers
+// ---------------------------------------------------------------------------------------------
+// center=True, pad_mode='reflect': out[b][i] = wav[b][reflect(i - pad)], row stride Lp (floats)
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ wav, float* __restrict__ out,
+                                                          int L, int pad, int Lp) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Lp) return;
+    float v = 0.f;
+    if (i < L + 2 * pad) {
+        int p = i - pad;
+        if (p < 0) p = -p;
+        if (p >= L) p = 2 * (L - 1) - p;
+        v = wav[(long)b * L + p];
+    }
+    out[(long)b * Lp + i] = v;
+}
+
+hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pad, hipStream_t s) {
+    const int Lp = (L + 2 * pad + 3) & ~3;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((Lp + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                       wav, out, L, pad, Lp);
+    return hipGetLastError();
+}
+
+// per-sample min / max (model/utils.py:25-26) over the n_rows x TF valid values; wavefront shuffles
+// then one LDS hop across the 4 waves.
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, float* __restrict__ mm,
+                                                     int planes, int TF, int n_rows) {
+    const int b = blockIdx.x;
+    const float4* xb = reinterpret_cast<const float4*>(x) + (long)b * planes * TF;
+    const int vplanes = (n_rows + 3) >> 2;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long i = threadIdx.x; i < (long)vplanes * TF; i += 256) {
+        const int pl = (int)(i / TF);
+        const float4 v = xb[i];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pl * 4 + e < n_rows) { mn = fminf(mn, vv[e]); mx = fmaxf(mx, vv[e]); }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    __shared__ float smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mm[b * 2 + 0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mm[b * 2 + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    }
+}
+
+hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)B), dim3(256), 0, s, logmel, mm, planes, TF, n_rows);
+    return hipGetLastError();
+}
+
+// (x - min) / (max - min), NaN -> 0 (model/utils.py:27-31 with min=0,max=1); mask -> -1
+// (model/diffwave.py:649-654); trim to T frames (:662); pad rows -> 0.
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, const float* __restrict__ mm,
+                                                        float* __restrict__ specP4, float* __restrict__ plain,
+                                                        int planes_in, int planes_out, int TF, int T, int n_rows,
+                                                        int mt0, int mt1, int mf0, int mf1) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.z, pl = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float mn = mm[b * 2], mx = mm[b * 2 + 1];
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pl * 4 < n_rows) {
+        const float4 v = reinterpret_cast<const float4*>(x)[((long)b * planes_in + pl) * TF + t];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        const bool en_t = mt0 >= 0, en_f = mf0 >= 0;
+        const bool in_t = (t >= mt0 && t < mt1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int f = pl * 4 + e;
+            if (f >= n_rows) continue;
+            float s = (vv[e] - mn) / (mx - mn);
+            s = s * (1.0f - 0.0f) + 0.0f;
+            if (s != s) s = 0.f;
+            const bool in_f = (f >= mf0 && f < mf1);
+            const bool masked = (en_t || en_f) && (!en_t || in_t) && (!en_f || in_f);
+            o[e] = masked ? -1.f : s;
+            if (plain) plain[((long)b * n_rows + f) * T + t] = o[e];
+        }
+    }
+    reinterpret_cast<float4*>(specP4)[((long)b * planes_out + pl) * T + t] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4, float* spec_plain, int B,
+                            int planes_in, int planes_out, int TF, int T, int n_rows, int mt0, int mt1, int mf0,
+                            int mf1, hipStream_t s) {
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)planes_out, (unsigned)B),
+                       dim3(256), 0, s, logmel, mm, specP4, spec_plain, planes_in, planes_out, TF, T, n_rows, mt0,
+                       mt1, mf0, mf1);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float v, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+
+}  // namespace dr

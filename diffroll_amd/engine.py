@@ -1,0 +1,179 @@
+"""Thin torch-tensor wrapper over the C-ABI: tensors in, raw HIP pointers out.
+
+PyTorch is used here only for device memory and streams; every computation is a hand-written
+gfx950 kernel behind libdiffroll_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _cabi
+from .schedule import build_embedding, make_schedule, posterior_coef_table
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _clamp_range(r: Optional[Sequence[int]], n: int) -> Tuple[int, int]:
+    """Python slice semantics of ``spec[..., int(r[0]):int(r[1])]`` -> clamped [lo, hi) or (-1,-1)."""
+    if not r:
+        return -1, -1
+    lo, hi, _ = slice(int(r[0]), int(r[1])).indices(n)
+    if hi < lo:
+        hi = lo
+    return lo, hi
+
+
+class Engine:
+    """One engine handle per (device, stream).  Not re-entrant."""
+
+    def __init__(self, *, residual_channels: int, residual_layers: int, kernel_size: int,
+                 dilation_base: int, dilation_bound: int, n_mels: int, timesteps: int,
+                 beta_start: float, beta_end: float, sample_rate: int = 16000, n_fft: int = 2048,
+                 hop_length: int = 512, f_min: float = 0.0, f_max: float = 8000.0,
+                 device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise EngineError("no ROCm device visible: diffroll_amd runs only on an MI355X (no CPU fallback)")
+        self.lib = _cabi.load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg = _cabi.DrConfig(
+            abi_version=_cabi.DR_ABI_VERSION, device=self.device.index,
+            residual_channels=residual_channels, residual_layers=residual_layers,
+            kernel_size=kernel_size, dilation_base=dilation_base, dilation_bound=dilation_bound,
+            n_mels=n_mels, timesteps=timesteps, sample_rate=sample_rate, n_fft=n_fft,
+            hop_length=hop_length, f_min=f_min, f_max=f_max, beta_start=beta_start, beta_end=beta_end)
+        self.timesteps = timesteps
+        self.n_mels = n_mels
+        self.hop_length = hop_length
+        self.n_fft = n_fft
+        h = C.c_void_p()
+        rc = self.lib.dr_create(C.byref(h), C.byref(self.cfg))
+        if rc != 0:
+            raise EngineError(f"dr_create failed ({rc}): {self.lib.dr_last_error(None).decode()}")
+        self.h = h
+        self.schedule = make_schedule(beta_start, beta_end, timesteps)
+        self._tables = (build_embedding(timesteps).contiguous().float(),
+                        posterior_coef_table(self.schedule).contiguous())
+        self._check(self.lib.dr_set_tables(
+            self.h, C.cast(self._tables[0].data_ptr(), C.POINTER(C.c_float)),
+            C.cast(self._tables[1].data_ptr(), C.POINTER(C.c_float))))
+        self.committed = False
+        self._keep = []   # tensors referenced by a captured graph must stay alive
+
+    # ------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.dr_last_error(self.h).decode()
+            if rc in (_cabi.DR_EINVAL, _cabi.DR_ENAME):
+                raise ValueError(msg)
+            raise EngineError(f"[{rc}] {msg}")
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def load_params(self, params: Dict[str, torch.Tensor]):
+        """Reference state_dict names/layouts (mel_layer.* buffers are ignored: the window and
+        filterbank are deterministic and rebuilt inside the engine)."""
+        for name, t in params.items():
+            if name.startswith("mel_layer.") or name.endswith("embedding"):
+                continue
+            a = t.detach().to("cpu", torch.float32).contiguous()
+            self._check(self.lib.dr_set_param(self.h, name.encode(),
+                                              C.cast(a.data_ptr(), C.POINTER(C.c_float)), a.numel()))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_commit(self.h, self._stream()))
+        self.committed = True
+
+    def _dev(self, t: torch.Tensor) -> torch.Tensor:
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(self.device, torch.float32).contiguous()
+        return t
+
+    def frontend(self, waveform: torch.Tensor, T_roll: int, inpainting_t=None, inpainting_f=None,
+                 return_spec: bool = True) -> Optional[torch.Tensor]:
+        wav = self._dev(waveform)
+        B, L = wav.shape
+        TF = L // self.hop_length + 1
+        T = min(T_roll, TF)
+        t0, t1 = _clamp_range(inpainting_t, TF)
+        f0, f1 = _clamp_range(inpainting_f, self.n_mels)
+        spec = torch.empty(B, self.n_mels, T, device=self.device, dtype=torch.float32) if return_spec else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_frontend(self.h, wav.data_ptr(), B, L, T_roll, t0, t1, f0, f1,
+                                             _ptr(spec), self._stream()))
+        return spec
+
+    def forward(self, x: torch.Tensor, t: int, uncond: bool) -> torch.Tensor:
+        """x (B, T, 88) -> x0 (B, T, 88)."""
+        x = self._dev(x)
+        B, T, K = x.shape
+        assert K == 88
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_forward(self.h, x.data_ptr(), B, T, int(t),
+                                            _cabi.COND_UNCOND if uncond else _cabi.COND_SPEC,
+                                            out.data_ptr(), self._stream()))
+        return out
+
+    def step(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], t: int, w: float = 0.0,
+             seed: int = 0, first_sample: int = 0) -> torch.Tensor:
+        """In place on x (B, T, 88) (must already be a contiguous fp32 device tensor)."""
+        assert x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
+        B, T, _ = x.shape
+        z = None if noise is None else self._dev(noise)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_step(self.h, _cabi.SAMPLERS[sampler], x.data_ptr(), _ptr(z), B, T, int(t),
+                                         float(w), int(seed), int(first_sample), self._stream()))
+        return x
+
+    def sample(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], w: float = 0.0,
+               seed: int = 0, first_sample: int = 0, use_graph: bool = True) -> torch.Tensor:
+        """Whole reverse chain in place on x (B, T, 88); noise (S, B, T, 88) or None (Philox)."""
+        assert x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
+        B, T, _ = x.shape
+        if noise is not None:
+            assert noise.device == self.device and noise.dtype == torch.float32 and noise.is_contiguous()
+            assert noise.shape[0] == self.timesteps and noise.numel() == self.timesteps * x.numel()
+        if use_graph:
+            self._keep = [x, noise]
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_sample(self.h, _cabi.SAMPLERS[sampler], x.data_ptr(), _ptr(noise), B, T,
+                                           float(w), int(seed), int(first_sample), 1 if use_graph else 0,
+                                           self._stream()))
+        return x
+
+    # ------------------------------------------------------------------ measurement helpers
+    def profile_enable(self, on: bool):
+        self._check(self.lib.dr_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> Tuple[int, float]:
+        n = C.c_int64(0)
+        ms = C.c_double(0.0)
+        self._check(self.lib.dr_profile_read(self.h, C.byref(n), C.byref(ms), 1 if reset else 0))
+        return n.value, ms.value
+
+    def bench_layer(self, layer: int, NB: int, T: int, t: int, n_cond: int):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_bench_layer(self.h, layer, NB, T, t, n_cond, self._stream()))

@@ -1,0 +1,326 @@
+"""Drop-in façade for the reference's sampling surface.
+
+``ClassifierFreeDiffRoll`` keeps the constructor keywords, ``hparams`` attribute access, method
+names, argument meaning, return conventions and error behaviour of the reference class
+(model/diffwave.py:579-686 on top of task/diffusion.py:219-256, :513-538, :765-790, :831-853,
+:943-1025), but every tensor operation runs in the HIP engine (diffroll_amd/csrc) through the
+C-ABI.  The torch modules created in the constructor are only PARAMETER CONTAINERS, so that a
+reference ``state_dict`` / Lightning checkpoint loads by name; they are never called.
+
+What is deliberately different from the reference:
+  * the mel front-end and the conditioner projections are computed once per clip, not twice per
+    step; the step-embedding MLP is a table built at load time;
+  * nothing is copied to the host inside the loop (task/diffusion.py:530) - ``predict_step`` /
+    ``sampling`` return device tensors; figures / gif / MIDI side effects are not produced;
+  * classifier-free guidance evaluates the conditional and unconditional branch as one 2B batch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+
+_SAMPLERS = ("ddpm_x0", "cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0")
+
+
+class AttrDict(dict):
+    """hparams-style attribute access (``self.hparams.sampling.w``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _attr(obj):
+    if isinstance(obj, dict):
+        return AttrDict({k: _attr(v) for k, v in obj.items()})
+    if hasattr(obj, "items") and not isinstance(obj, (str, bytes)):   # OmegaConf DictConfig & friends
+        try:
+            return AttrDict({k: _attr(v) for k, v in obj.items()})
+        except Exception:
+            return obj
+    return obj
+
+
+def _conv1d(cin, cout, k):
+    layer = nn.Conv1d(cin, cout, k)
+    nn.init.kaiming_normal_(layer.weight)        # model/diffwave.py:41-44
+    return layer
+
+
+class _DiffusionEmbedding(nn.Module):            # parameter container for model/diffwave.py:58-63
+    def __init__(self):
+        super().__init__()
+        self.projection1 = nn.Linear(128, 512)
+        self.projection2 = nn.Linear(512, 512)
+
+
+class _ResidualBlock(nn.Module):                 # parameter container for model/diffwave.py:108-132
+    def __init__(self, n_mels, residual_channels, kernel_size):
+        super().__init__()
+        self.dilated_conv = _conv1d(residual_channels, 2 * residual_channels, kernel_size)
+        self.diffusion_projection = nn.Linear(512, residual_channels)
+        self.conditioner_projection = _conv1d(n_mels, 2 * residual_channels, 1)
+        self.output_projection = _conv1d(residual_channels, 2 * residual_channels, 1)
+
+
+class ClassifierFreeDiffRoll(nn.Module):
+    def __init__(self,
+                 residual_channels,
+                 unconditional,
+                 condition,
+                 n_mels,
+                 norm_args,
+                 residual_layers=30,
+                 kernel_size=3,
+                 dilation_base=1,
+                 dilation_bound=4,
+                 spec_args={},
+                 spec_dropout=0.5,
+                 inpainting_t=None,
+                 inpainting_f=None,
+                 # SpecRollDiffusion (task/diffusion.py:220-232)
+                 lr=1e-4,
+                 timesteps=200,
+                 loss_type="l2",
+                 loss_keys=("diffusion_loss",),
+                 beta_start=1e-4,
+                 beta_end=0.02,
+                 frame_threshold=0.5,
+                 training=None,
+                 sampling=None,
+                 debug=False,
+                 generation_filter=0.0,
+                 device=None):
+        super().__init__()
+        if condition not in ("fixed",):
+            if condition in ("trainable_spec", "trainable_z"):
+                raise NotImplementedError(
+                    f"condition='{condition}' is outside the sampling hot path (SURVEY.md 2.1 #9)")
+            raise ValueError(f"unrecognized condition '{condition}'")        # model/diffwave.py:610
+        if unconditional:
+            raise NotImplementedError("unconditional=True (no conditioner) is not on the sampling hot path")
+        sampling = _attr(sampling if sampling is not None else {"type": "cfdg_ddpm_x0", "w": 0.0})
+        training = _attr(training if training is not None else {"mode": "x_0"})
+        spec_args = _attr(dict(spec_args))
+        if sampling.type not in _SAMPLERS:
+            if hasattr(self, sampling.type) or sampling.type in ("ddpm", "ddim", "ddim_x0", "ddim2ddpm", "cfdg_ddim_x0"):
+                raise NotImplementedError(f"sampler '{sampling.type}' is not part of the hot path (SURVEY.md 8f-3)")
+            raise AttributeError(sampling.type)                               # getattr at task/diffusion.py:255
+        self.hparams = AttrDict(
+            residual_channels=residual_channels, unconditional=unconditional, condition=condition,
+            n_mels=n_mels, norm_args=list(norm_args), residual_layers=residual_layers,
+            kernel_size=kernel_size, dilation_base=dilation_base, dilation_bound=dilation_bound,
+            spec_args=spec_args, spec_dropout=spec_dropout, inpainting_t=inpainting_t,
+            inpainting_f=inpainting_f, lr=lr, timesteps=timesteps, loss_type=loss_type,
+            loss_keys=list(loss_keys), beta_start=beta_start, beta_end=beta_end,
+            frame_threshold=frame_threshold, training=training, sampling=sampling, debug=debug,
+            generation_filter=generation_filter)
+        self.spec_dropout = spec_dropout
+
+        # parameter containers, same names/shapes/initialisation as the reference
+        self.input_projection = _conv1d(88, residual_channels, 1)
+        self.diffusion_embedding = _DiffusionEmbedding()
+        self.residual_layers = nn.ModuleList(
+            [_ResidualBlock(n_mels, residual_channels, kernel_size) for _ in range(residual_layers)])
+        self.skip_projection = _conv1d(residual_channels, residual_channels, 1)
+        self.output_projection = _conv1d(residual_channels, 88, 1)
+        nn.init.zeros_(self.output_projection.weight)                         # model/diffwave.py:630
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+        sa = spec_args
+        self._engine_kwargs = dict(
+            residual_channels=residual_channels, residual_layers=residual_layers,
+            kernel_size=kernel_size, dilation_base=dilation_base, dilation_bound=dilation_bound,
+            n_mels=n_mels, timesteps=timesteps, beta_start=beta_start, beta_end=beta_end,
+            sample_rate=int(sa.get("sample_rate", 16000)), n_fft=int(sa.get("n_fft", 2048)),
+            hop_length=int(sa.get("hop_length", 512)), f_min=float(sa.get("f_min", 0.0)),
+            f_max=float(sa.get("f_max", 8000.0)))
+        for key in ("center", "normalized"):
+            if key in sa and not sa[key]:
+                raise NotImplementedError(f"spec_args.{key}=False is not supported (config/spec/mel.yaml)")
+        if sa.get("pad_mode", "reflect") != "reflect":
+            raise NotImplementedError("only pad_mode='reflect' is supported (config/spec/mel.yaml)")
+        self._device = device
+        self._engine: Optional[Engine] = None
+        self._dirty = True
+        self._fe_key = None
+        self._fe_spec = None
+        self.reverse_diffusion = getattr(self, sampling.type)                  # task/diffusion.py:255
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = Engine(device=self._device, **self._engine_kwargs)
+            self._dirty = True
+        if self._dirty:
+            self._engine.load_params({k: v for k, v in self.state_dict().items()})
+            self._dirty = False
+            self._fe_key = None
+        return self._engine
+
+    # schedule vectors, exposed like the reference's attributes (task/diffusion.py:239-256)
+    def __getattr__(self, name):
+        if name in ("betas", "alphas", "sqrt_recip_alphas", "sqrt_alphas_cumprod",
+                    "sqrt_one_minus_alphas_cumprod", "posterior_variance"):
+            from .schedule import make_schedule
+            hp = self.__dict__["hparams"]
+            return make_schedule(hp.beta_start, hp.beta_end, hp.timesteps)[name]
+        return super().__getattr__(name)
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        own = {k: v for k, v in state_dict.items()
+               if not k.startswith("mel_layer.") and k != "diffusion_embedding.embedding"}
+        out = super().load_state_dict(own, strict=strict)
+        self._dirty = True
+        return out
+
+    def to(self, *args, **kwargs):           # parameters stay on the host; the engine owns device copies
+        for a in args:
+            if isinstance(a, (str, torch.device)) and torch.device(a).type == "cuda":
+                self._device = torch.device(a)
+        if "device" in kwargs and torch.device(kwargs["device"]).type == "cuda":
+            self._device = torch.device(kwargs["device"])
+        return self
+
+    def cuda(self, device=None):
+        self._device = torch.device("cuda", device if device is not None else torch.cuda.current_device())
+        return self
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides):
+        """Lightning-style: ``{'state_dict', 'hyper_parameters'}``; keyword overrides win
+        (sampling.py:54-65).  Reading a real Lightning .ckpt needs its pickled OmegaConf classes
+        importable; a plain ``torch.save({'state_dict':..., 'hyper_parameters': dict})`` always works."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        m = cls(**hp)
+        m.load_state_dict(ckpt["state_dict"], strict=False)
+        return m
+
+    # ------------------------------------------------------------------ forward
+    def _frontend(self, waveform: torch.Tensor, T_roll: int, inpainting_t, inpainting_f) -> torch.Tensor:
+        eng = self.engine
+        key = (waveform.data_ptr(), tuple(waveform.shape), waveform._version, T_roll,
+               tuple(inpainting_t) if inpainting_t else None, tuple(inpainting_f) if inpainting_f else None)
+        if key != self._fe_key:
+            self._fe_spec = eng.frontend(waveform, T_roll, inpainting_t, inpainting_f)
+            self._fe_key = key
+            self._fe_wave = waveform    # keep alive so data_ptr cannot be recycled
+        return self._fe_spec
+
+    def forward(self, x_t, waveform, diffusion_step, sampling=False, inpainting_t=None, inpainting_f=None):
+        """(x_t (B,1,T,88), waveform (B,L), diffusion_step (B,) int) -> (x0_pred (B,1,T,88), spec (B,n_mels,T'))
+        with T' = min(T, L//hop + 1) (model/diffwave.py:637-686, eval mode)."""
+        eng = self.engine
+        if diffusion_step.dtype not in (torch.int32, torch.int64):
+            raise NotImplementedError("fractional diffusion steps (lerp branch, model/diffwave.py:76-81) are off-path")
+        t = int(diffusion_step.flatten()[0].item())
+        if not bool((diffusion_step == t).all()):
+            raise NotImplementedError("per-sample diffusion steps are not used by the samplers (task/diffusion.py:947)")
+        B, _, T, K = x_t.shape
+        if sampling is True:
+            TF = waveform.shape[-1] // eng.hop_length + 1
+            Tm = min(T, TF)
+            spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
+        else:
+            spec = self._frontend(waveform, T, inpainting_t, inpainting_f)
+            Tm = spec.shape[-1]
+        x = x_t.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous()
+        x0 = eng.forward(x, t, uncond=(sampling is True))
+        return x0.unsqueeze(1), spec
+
+    # ------------------------------------------------------------------ samplers (one step)
+    def _one_step(self, sampler: str, x, waveform, t_index: int, noise=None):
+        eng = self.engine
+        B, _, T, _ = x.shape
+        spec = None
+        if sampler != "generation_ddpm_x0":
+            it = self.hparams.inpainting_t if sampler == "inpainting_ddpm_x0" else None
+            i_f = self.hparams.inpainting_f if sampler == "inpainting_ddpm_x0" else None
+            spec = self._frontend(waveform, T, it, i_f)
+            Tm = spec.shape[-1]
+        else:
+            Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
+        xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0") else 0.0
+        z = None
+        if noise is not None:
+            z = noise.to(eng.device, torch.float32).reshape(B, Tm, 88).contiguous()
+        elif t_index > 0:
+            z = torch.randn(B, Tm, 88, device=eng.device)   # reference: torch.randn_like(x), global generator
+        eng.step(sampler, xx, z, t_index, w)
+        if spec is None:
+            spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)   # generation returns the uncond spec
+        return xx.unsqueeze(1), spec
+
+    def ddpm_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:831-853."""
+        return self._one_step("ddpm_x0", x, waveform, t_index, noise)
+
+    def cfdg_ddpm_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:943-969."""
+        return self._one_step("cfdg_ddpm_x0", x, waveform, t_index, noise)
+
+    def generation_ddpm_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:971-997."""
+        return self._one_step("generation_ddpm_x0", x, waveform, t_index, noise)
+
+    def inpainting_ddpm_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:999-1025."""
+        return self._one_step("inpainting_ddpm_x0", x, waveform, t_index, noise)
+
+    # ------------------------------------------------------------------ whole chain
+    @torch.no_grad()
+    def sample(self, x_T, waveform=None, noise=None, seed: int = 0, first_sample: int = 0,
+               use_graph: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The reverse chain t = timesteps-1 .. 0 (task/diffusion.py:528-534) on the device with no
+        host round trip.  x_T (B,1,T,88); noise: None (on-device Philox keyed by seed and global
+        sample index) or (timesteps, B, 1, T, 88) injected z's (row t is used at step t >= 1).
+        Returns (roll (B,1,T',88), spec (B,n_mels,T'))."""
+        eng = self.engine
+        sampler = self.hparams.sampling.type
+        B, _, T, _ = x_T.shape
+        if sampler != "generation_ddpm_x0":
+            if waveform is None:
+                raise ValueError("waveform is required for conditional samplers")
+            it = self.hparams.inpainting_t if sampler == "inpainting_ddpm_x0" else None
+            i_f = self.hparams.inpainting_f if sampler == "inpainting_ddpm_x0" else None
+            spec = self._frontend(waveform, T, it, i_f)
+            Tm = spec.shape[-1]
+        else:
+            Tm = T if waveform is None else min(T, waveform.shape[-1] // eng.hop_length + 1)
+            spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
+        x = x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        z = None
+        if noise is not None:
+            S = self.hparams.timesteps
+            z = noise.to(eng.device, torch.float32).reshape(S, B, T, 88)[:, :, :Tm, :].contiguous()
+        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0") else 0.0
+        eng.sample(sampler, x, z, w, seed, first_sample, use_graph)
+        return x.unsqueeze(1), spec
+
+    def predict_step(self, batch, batch_idx=0):
+        """batch = (x_T, waveform[, ...]) as built by sampling.py:27-46.  Returns the final roll
+        (B,1,T,88) (the reference returns nothing and writes figures/MIDI instead)."""
+        noise, waveform = batch[0], batch[1]
+        roll, _ = self.sample(noise, waveform, seed=batch_idx)
+        return roll
+
+    def sampling(self, batch, batch_idx=0):
+        """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""
+        frame = batch["frame"]
+        x_T = torch.randn(frame.shape[0], 1, frame.shape[1], frame.shape[2], device=self.engine.device)
+        return self.sample(x_T, batch["audio"], seed=batch_idx)

@@ -1,0 +1,69 @@
+"""Host-side constant tables of the sampler (tiny, built once per model).
+
+The reference keeps these as plain CPU tensors computed in its constructor
+(task/diffusion.py:239-256) and evaluates the per-step scalars inline at every step
+(:957-967).  They are evaluated here with the same torch fp32 expressions so the
+coefficients the update kernel reads are bit-equal to the reference's, then handed to the
+engine through dr_set_tables().
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+
+def linear_beta_schedule(beta_start: float, beta_end: float, timesteps: int) -> torch.Tensor:
+    """task/diffusion.py:28-29."""
+    return torch.linspace(beta_start, beta_end, timesteps)
+
+
+def make_schedule(beta_start: float, beta_end: float, timesteps: int) -> Dict[str, torch.Tensor]:
+    """The six schedule vectors of SpecRollDiffusion.__init__ (task/diffusion.py:239-256)."""
+    betas = linear_beta_schedule(beta_start, beta_end, timesteps)
+    alphas = 1. - betas
+    alphas_cumprod = torch.cumprod(alphas, axis=0)
+    alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.0)
+    return {
+        "betas": betas,
+        "alphas": alphas,
+        "sqrt_recip_alphas": torch.sqrt(1.0 / alphas),
+        "sqrt_alphas_cumprod": torch.sqrt(alphas_cumprod),
+        "sqrt_one_minus_alphas_cumprod": torch.sqrt(1. - alphas_cumprod),
+        "posterior_variance": betas * (1. - alphas_cumprod_prev) / (1 - alphas_cumprod),
+    }
+
+
+def posterior_coef_table(sch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """(S, 5) fp32: [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]**2 - sigma**2), sqrt_acp[t],
+    sqrt_1m_acp[t], sigma] - the scalars of the x0-prediction DDPM update,
+    task/diffusion.py:957-967 (identical in ddpm_x0 / cfdg / generation / inpainting).
+    Row 0 only uses column 2 (x = x0 / sqrt_acp[0]; no noise)."""
+    sac = sch["sqrt_alphas_cumprod"]
+    s1m = sch["sqrt_one_minus_alphas_cumprod"]
+    alphas = sch["alphas"]
+    S = sac.shape[0]
+    out = torch.zeros(S, 5, dtype=torch.float32)
+    for t in range(S):
+        if t == 0:
+            sigma = (1 / s1m[t]) * torch.sqrt(1 - alphas[t])
+            out[t, 2] = sac[t]
+            out[t, 3] = s1m[t]
+            out[t, 4] = sigma
+        else:
+            sigma = (s1m[t - 1] / s1m[t]) * torch.sqrt(1 - alphas[t])
+            out[t, 0] = sac[t - 1]
+            out[t, 1] = torch.sqrt(1 - sac[t - 1] ** 2 - sigma ** 2)
+            out[t, 2] = sac[t]
+            out[t, 3] = s1m[t]
+            out[t, 4] = sigma
+    return out
+
+
+def build_embedding(max_steps: int) -> torch.Tensor:
+    """Sinusoidal step table (S, 128) of DiffusionEmbedding (model/diffwave.py:83-88)."""
+    steps = torch.arange(max_steps).unsqueeze(1)
+    dims = torch.arange(64).unsqueeze(0)
+    table = steps * 10.0 ** (dims * 4.0 / 63.0)
+    return torch.cat([torch.sin(table), torch.cos(table)], dim=1)

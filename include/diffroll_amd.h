@@ -1,0 +1,165 @@
+/*
+ * diffroll_amd.h - C-ABI of the MI355X-native DiffRoll sampling engine.
+ *
+ * The reference (sony/DiffRoll) has NO plugin / FFI layer: its sampling path sits behind the
+ * Python methods of a LightningModule.  This header is therefore the boundary a maintainer
+ * would bind UNDER those methods (ctypes stub: INTEGRATION.md).  Each entry point names the
+ * reference interface it replaces (paths relative to the reference checkout):
+ *
+ *   dr_create / dr_set_param / dr_commit   ClassifierFreeDiffRoll.__init__ + load_from_checkpoint
+ *                                          (model/diffwave.py:580-635, sampling.py:54-65) and the
+ *                                          schedule of SpecRollDiffusion.__init__
+ *                                          (task/diffusion.py:239-256)
+ *   dr_frontend                            mel_layer -> log -> normalize_spec -> inpainting mask ->
+ *                                          trim (model/diffwave.py:643-662, model/utils.py:21-32)
+ *   dr_forward                             ClassifierFreeDiffRoll.forward after the front-end
+ *                                          (model/diffwave.py:664-686, ResidualBlock :134-151)
+ *   dr_step                                cfdg_ddpm_x0 / generation_ddpm_x0 / inpainting_ddpm_x0 /
+ *                                          ddpm_x0 (task/diffusion.py:943-1025, :831-853)
+ *   dr_sample                              the loop of predict_step / sampling
+ *                                          (task/diffusion.py:528-534, :779-788)
+ *
+ * Conventions: plain C, no torch types.  All tensor arguments are BORROWED device pointers to
+ * contiguous fp32 (hipMalloc'd / torch ROCm memory on the engine's device); outputs are written
+ * into caller-allocated buffers.  `stream` is a hipStream_t passed as void* (e.g.
+ * torch.cuda.current_stream().cuda_stream).  Every function returns 0 on success or a negative
+ * DR_E* code and never throws; the message is available from dr_last_error().  An engine handle
+ * is not re-entrant: one handle per (device, stream), one host thread at a time.
+ */
+#ifndef DIFFROLL_AMD_H
+#define DIFFROLL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_ABI_VERSION 1
+
+enum {
+    DR_OK = 0,
+    DR_EINVAL = -1,   /* bad argument / shape */
+    DR_ESTATE = -2,   /* call order (e.g. dr_forward before dr_commit / dr_frontend) */
+    DR_EHIP = -3,     /* a HIP runtime call failed (message has the HIP error string) */
+    DR_ENOMEM = -4,
+    DR_ENAME = -5     /* unknown parameter name / wrong shape in dr_set_param */
+};
+
+/* samplers: task/diffusion.py, bound at :255 by hparams.sampling.type */
+enum {
+    DR_SAMPLER_DDPM_X0 = 0,        /* :831-853  one conditional evaluation            */
+    DR_SAMPLER_CFDG_DDPM_X0 = 1,   /* :943-969  conditional + unconditional, weight w */
+    DR_SAMPLER_GENERATION_DDPM_X0 = 2, /* :971-997  one unconditional evaluation (spec = -1) */
+    DR_SAMPLER_INPAINTING_DDPM_X0 = 3  /* :999-1025 as cfdg; spectrogram frames/bins masked by
+                                          dr_frontend's mask arguments */
+};
+
+/* which spectrogram a dr_forward evaluation sees (model/diffwave.py:656-660) */
+enum {
+    DR_COND_SPEC = 0,    /* the spectrogram of the last dr_frontend call   */
+    DR_COND_UNCOND = 1   /* sampling=True: spectrogram == -1 everywhere     */
+};
+
+/* hyper-parameters: config/model/ClassifierFreeDiffRoll.yaml:1-15, config/task/<task>.yaml,
+ * config/spec/mel.yaml:1-10, config/sampling.yaml:1-4 */
+typedef struct dr_config {
+    int32_t abi_version;        /* DR_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal */
+    int32_t residual_channels;  /* 512 (multiple of 64) */
+    int32_t residual_layers;    /* 15 */
+    int32_t kernel_size;        /* odd: 3 / 9 / 15 */
+    int32_t dilation_base;      /* 2 */
+    int32_t dilation_bound;     /* 4 */
+    int32_t n_mels;             /* 229 */
+    int32_t timesteps;          /* 200 */
+    int32_t sample_rate;        /* 16000 */
+    int32_t n_fft;              /* 2048 (multiple of 32) */
+    int32_t hop_length;         /* 512  (multiple of 4) */
+    float f_min;                /* 0 */
+    float f_max;                /* 8000 */
+    float beta_start;           /* 1e-4  (informational; the coefficient table is passed in) */
+    float beta_end;             /* 0.02 */
+} dr_config;
+
+typedef struct dr_engine dr_engine;
+
+/* version of the loaded library (== DR_ABI_VERSION of the header it was built with) */
+int dr_abi_version(void);
+
+int dr_create(dr_engine** out, const dr_config* cfg);
+void dr_destroy(dr_engine* e);
+const char* dr_last_error(const dr_engine* e);   /* e may be NULL: error of the last dr_create */
+
+/*
+ * Hand over one parameter tensor by its reference state_dict name, in the
+ * reference's own layout, from HOST memory (copied):
+ *   input_projection.{weight (C,88,1), bias (C)}
+ *   diffusion_embedding.projection1.{weight (512,128), bias}, .projection2.{weight (512,512), bias}
+ *   residual_layers.<i>.dilated_conv.{weight (2C,C,k), bias (2C)}
+ *   residual_layers.<i>.diffusion_projection.{weight (C,512), bias (C)}
+ *   residual_layers.<i>.conditioner_projection.{weight (2C,n_mels,1), bias (2C)}
+ *   residual_layers.<i>.output_projection.{weight (2C,C,1), bias (2C)}
+ *   skip_projection.{weight (C,C,1), bias (C)},  output_projection.{weight (88,C,1), bias (88)}
+ * numel must match the shape implied by the config.  Unknown names -> DR_ENAME.
+ */
+int dr_set_param(dr_engine* e, const char* name, const float* host_data, size_t numel);
+
+/*
+ * Host-built tables (same torch expressions as the reference, so bit-equal):
+ *   embedding  (timesteps, 128)  DiffusionEmbedding._build_embedding (model/diffwave.py:83-88)
+ *   coef       (timesteps, 5)    per-step scalars of task/diffusion.py:957-967:
+ *                                [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]^2 - sigma^2), sqrt_acp[t],
+ *                                 sqrt_1m_acp[t], sigma];  row 0: [., ., sqrt_acp[0], ., .]
+ */
+int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_coef);
+
+/* Pack weights for the kernels, upload, and build the hoisted tables on the device (the
+ * (timesteps, layers, C) step-embedding projections; the unconditional conditioner constants).
+ * Requires every parameter and both tables.  Synchronises `stream`. */
+int dr_commit(dr_engine* e, void* stream);
+
+/*
+ * Front-end, once per clip batch.  d_wav (B, L) -> d_spec_out (B, n_mels, T) with
+ * T = min(T_roll, L / hop + 1); also builds the per-layer conditioner tensors the residual
+ * blocks consume, for this batch.  Mask: spectrogram[f0:f1, t0:t1] = -1 after normalisation
+ * (pass t0 = t1 = -1 / f0 = f1 = -1 for "no mask on that axis"; model/diffwave.py:649-654).
+ * d_spec_out may be NULL.
+ */
+int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll,
+                int mask_t0, int mask_t1, int mask_f0, int mask_f1,
+                float* d_spec_out, void* stream);
+
+/* One network evaluation at diffusion step t: d_x (B, T, 88) [the reference's (B,1,T,88)] ->
+ * d_x0_out (B, T, 88).  cond = DR_COND_SPEC needs a preceding dr_frontend with the same B, T. */
+int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond,
+               float* d_x0_out, void* stream);
+
+/* One reverse-diffusion step t (in place on d_x).  d_noise (B, T, 88) is the z of that step
+ * (ignored at t == 0); NULL -> on-device Philox keyed by (seed, first_sample + b, t). */
+int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, int t,
+            float w, uint64_t seed, int first_sample, void* stream);
+
+/*
+ * The whole reverse chain t = timesteps-1 .. 0, in place on d_x, no host synchronisation.
+ * d_noise: (timesteps, B, T, 88) injected noise (row t used at step t >= 1) or NULL for Philox.
+ * use_graph != 0: the chain is captured once into a hipGraph (cached per argument set) and
+ * replayed.  Needs dr_frontend first unless sampler == DR_SAMPLER_GENERATION_DDPM_X0.
+ */
+int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T,
+              float w, uint64_t seed, int first_sample, int use_graph, void* stream);
+
+/* Timing of the dominant kernel (dilated conv + gate) inside dr_sample, measured with HIP events
+ * on the launch stream when enabled: returns launches and total milliseconds since last reset. */
+int dr_profile_enable(dr_engine* e, int on);
+int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset);
+
+/* Standalone launch of the fused dilated-conv+gate kernel of layer `layer` on the engine's
+ * workspace activations (for micro-benchmarks / roofline): returns 0. */
+int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFROLL_AMD_H */
