@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: piano-roll frames/s for a 200-step reverse-diffusion sample.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ClassifierFreeDiffRoll k=9, C=512, 15 layers, cfdg_ddpm_x0 w=0.5,
+200 steps, batch 16 per GPU of 4 s / 16 kHz synthetic clips (L=64000 -> T=125 frames), fp32,
+random-init weights.  One "step" of this benchmark = one whole sample of the local batch:
+front-end (STFT/mel/normalise/conditioner projections) + the 200-step hipGraph-captured chain +
+the RCCL gather of the finished rolls + the device->host copy on rank 0.  Inputs are resident in HBM
+when the timed region starts.  Multi-GPU is weak scaling: every rank runs its own 16 clips, the only
+collective is the final all-gather.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (dilated conv + gate implicit
+GEMM on v_mfma_f32_32x32x2_f32): algorithmic FLOPs per launch / mean launch duration measured with
+HIP events on the launch stream in an extra, event-instrumented eager pass of the same chain run
+right after the timed region.  `cpu_baseline` is the CPU oracle (a port of the reference math, torch
+CPU fp32) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HP = dict(residual_channels=512, residual_layers=15, kernel_size=9, dilation_base=2, dilation_bound=4,
+          n_mels=229, timesteps=200, beta_start=1e-4, beta_end=0.02, sample_rate=16000, n_fft=2048,
+          hop_length=512, f_min=0.0, f_max=8000.0)
+B_LOCAL = 16
+L_SAMPLES = 64000
+W_CFG = 0.5
+SAMPLER = "cfdg_ddpm_x0"
+PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak
+
+
+def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0):
+    from diffroll_amd import ClassifierFreeDiffRoll
+    torch.manual_seed(seed)
+    m = ClassifierFreeDiffRoll(
+        residual_channels=hp["residual_channels"], unconditional=False, condition="fixed",
+        n_mels=hp["n_mels"], norm_args=[0, 1, "imagewise"], residual_layers=hp["residual_layers"],
+        kernel_size=hp["kernel_size"], dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
+        spec_args=dict(sample_rate=hp["sample_rate"], n_fft=hp["n_fft"], hop_length=hp["hop_length"],
+                       n_mels=hp["n_mels"], f_min=hp["f_min"], f_max=hp["f_max"], center=True,
+                       normalized=True, pad_mode="reflect"),
+        spec_dropout=0.1, timesteps=hp["timesteps"], beta_start=hp["beta_start"], beta_end=hp["beta_end"],
+        training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, device=device)
+    # the reference zero-initialises the output projection (model/diffwave.py:630): re-draw it so the
+    # synthetic network is input dependent
+    torch.nn.init.normal_(m.output_projection.weight, 0.0, 0.02)
+    m._dirty = True
+    return m
+
+
+def cpu_baseline(model, budget_s=12.0, max_steps=6):
+    """The oracle (CPU port of the reference arithmetic) on this box's host cores, bounded sample."""
+    from oracle import diffroll_ref as R           # checker / baseline only - never the product path
+    params = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    hp = dict(HP)
+    T = L_SAMPLES // hp["hop_length"]
+    g = torch.Generator().manual_seed(1)
+    wav = 0.1 * torch.randn(B_LOCAL, L_SAMPLES, generator=g)
+    x = torch.randn(B_LOCAL, 1, T, 88, generator=g)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    table = R.build_embedding(hp["timesteps"])
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        spec = R.frontend(wav, hp, T)
+        t_front = time.perf_counter() - t0
+        n = 0
+        t0 = time.perf_counter()
+        while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
+            t_index = hp["timesteps"] - 1 - n
+            z = torch.randn(x.shape, generator=g)
+            x = R.reverse_step(params, hp, sch, SAMPLER, x, spec, t_index, z, W_CFG, table)
+            n += 1
+        t_steps = time.perf_counter() - t0
+    per_step = t_steps / n
+    total = t_front + per_step * hp["timesteps"]
+    return {
+        "value": round(B_LOCAL * T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{n} of 200 reverse steps (2 network evaluations each) at B={B_LOCAL},T={T} + one front-end, "
+                  f"{t_steps + t_front:.1f} s of CPU work, extrapolated to the 200-step chain",
+        "os_cpu_count": os.cpu_count(), "s_per_step": round(per_step, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from diffroll_amd.distributed import gather_rolls
+
+    model = build_model(device)
+    T = L_SAMPLES // HP["hop_length"]
+    S = HP["timesteps"]
+    # synthetic inputs, resident in HBM; global sample index = rank * B_LOCAL + b
+    g = torch.Generator().manual_seed(1000 + rank)
+    wav = (0.1 * torch.randn(B_LOCAL, L_SAMPLES, generator=g)).to(device)
+    x_T = torch.randn(B_LOCAL, 1, T, 88, generator=g).to(device)
+    model.engine   # create + commit (weight packing / upload) outside the timed region
+
+    def one_step():
+        model._fe_key = None                                   # front-end is part of every sample
+        roll, _ = model.sample(x_T, wav, seed=0, first_sample=rank * B_LOCAL)   # on-device Philox noise
+        full = gather_rolls(roll)                              # RCCL all-gather (no-op at N=1)
+        if rank == 0:
+            return full.cpu()
+        return None
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+
+    frames = world * B_LOCAL * T * args.steps
+    result = {
+        "metric": "piano-roll frames/sec (200-step sample)", "value": round(frames / dt, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: ClassifierFreeDiffRoll k=9 C=512 L=15, cfdg_ddpm_x0 w=0.5, "
+                               "200 steps, batch 16 per GPU, 4 s @16 kHz clips (T=125), random-init weights, "
+                               "Philox noise, front-end + chain + gather + D2H per step",
+                   "batch_per_gpu": B_LOCAL, "frames_per_clip": T, "diffusion_steps": S,
+                   "kernel_size": HP["kernel_size"], "sampler": SAMPLER, "w": W_CFG,
+                   "parallelism": f"batch-shard x{world}", "graph": True},
+    }
+    if rank == 0:
+        assert out is not None and bool(torch.isfinite(out).all()) and out.shape == (world * B_LOCAL, 1, T, 88)
+
+    if rank == 0 and not args.no_roofline:
+        eng = model.engine
+        eng.profile_enable(True)
+        model._fe_key = None
+        model.sample(x_T, wav, seed=0, first_sample=0, use_graph=False)
+        launches, ms = eng.profile_read(reset=True)
+        eng.profile_enable(False)
+        k = HP["kernel_size"]
+        C = HP["residual_channels"]
+        flops_per_frame = 2.0 * C * (2 * C) * k            # 2*512*1024*k per frame per layer
+        frames_per_launch = 2 * B_LOCAL * T                # conditional + unconditional batch
+        avg_s = ms * 1e-3 / max(launches, 1)
+        achieved = flops_per_frame * frames_per_launch / avg_s / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_kernel<2,EPI_GATE> (dilated conv k=9 + conditioner + gate)",
+            "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+            "launches": launches, "avg_launch_us": round(avg_s * 1e6, 2),
+            "flops_per_launch": flops_per_frame * frames_per_launch,
+            "share_of_step_time": round((ms * 1e-3) / (dt / args.steps), 4),
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(model)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -606,10 +606,14 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     if ((size_t)B * mel_planes * 4 * T > e->fe_cap_spec) { if ((rc = dev_alloc(e, &e->specP4, (size_t)B * mel_planes * 4 * T))) return rc; e->fe_cap_spec = (size_t)B * mel_planes * 4 * T; }
     if ((size_t)B * 2 > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, (size_t)B * 2))) return rc; e->fe_cap_mm = (size_t)B * 2; }
     const size_t cond_need = (size_t)e->L * B * 2 * Cp * T;
-    if (cond_need > e->cond_cap) { if ((rc = dev_alloc(e, &e->cond, cond_need))) return rc; e->cond_cap = cond_need; }
-    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }   // cond layout may change
-    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-    e->gkey = GraphKey{};
+    bool cond_moved = false;
+    if (cond_need > e->cond_cap) { if ((rc = dev_alloc(e, &e->cond, cond_need))) return rc; e->cond_cap = cond_need; cond_moved = true; }
+    if (cond_moved || B != e->fe_B || T != e->fe_T) {
+        // a captured chain bakes the conditioner pointers / strides: drop it when they change
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        e->gkey = GraphKey{};
+    }
 
     // 1. center / reflect padding
     HIPCHK(e, launch_reflect_pad(d_wav, e->wav_pad, B, L, pad, st));

@@ -1,0 +1,79 @@
+"""Batch sharding over the GPUs of one node (one process per GPU, torch.distributed 'nccl' = RCCL).
+
+Each clip's reverse chain is independent (no cross-sample operation anywhere on the path), so the
+batch is partitioned contiguously across ranks, weights are replicated, nothing is exchanged inside
+the 200-step loop, and the ONLY collective is one all-gather of the finished rolls over xGMI
+(<= 3.6 MB per rank: latency bound).  The reference itself never gathers (Lightning only shards the
+DataLoader under ``Trainer(gpus=N)``, sampling.py:70); the gather exists so rank 0 can return the
+whole batch.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def world() -> Tuple[int, int]:
+    d = _dist()
+    return (d.get_rank(), d.get_world_size()) if d else (0, 1)
+
+
+def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of n samples for ``rank``; the first n % world ranks get one extra."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_rolls(local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather equally sized local rolls (b, 1, T, 88) into (world*b, 1, T, 88), rank-major."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return local
+    ws = d.get_world_size(group)
+    local = local.contiguous()
+    out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    d.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def gather_rolls_uneven(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """As gather_rolls for shard_bounds() partitions whose sizes differ by one: pad to the largest
+    shard, gather, and drop the padding."""
+    d = _dist()
+    if d is None or d.get_world_size(group) == 1:
+        return local
+    ws = d.get_world_size(group)
+    mx = (n_total + ws - 1) // ws
+    pad = mx - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    full = gather_rolls(local, group)
+    parts = []
+    for r in range(ws):
+        lo, hi = shard_bounds(n_total, r, ws)
+        parts.append(full[r * mx: r * mx + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def sample_sharded(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], noise: Optional[torch.Tensor] = None,
+                   seed: int = 0, group=None) -> torch.Tensor:
+    """Every rank passes the SAME global batch (x_T (B,1,T,88), waveform (B,L), optional injected noise
+    (S,B,1,T,88)); each runs its contiguous shard and all ranks return the full (B,1,T',88) result.
+    Philox noise is keyed by the global sample index, so the result does not depend on the world size."""
+    rank, ws = world()
+    B = x_T.shape[0]
+    lo, hi = shard_bounds(B, rank, ws)
+    wav = None if waveform is None else waveform[lo:hi]
+    z = None if noise is None else noise[:, lo:hi]
+    if hi > lo:
+        roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
+    else:
+        roll = x_T.new_zeros((0,) + tuple(x_T.shape[1:])).to(model.engine.device)
+    return gather_rolls_uneven(roll, B, group)

@@ -156,6 +156,7 @@ class ClassifierFreeDiffRoll(nn.Module):
         self._dirty = True
         self._fe_key = None
         self._fe_spec = None
+        self._xbuf = {}
         self.reverse_diffusion = getattr(self, sampling.type)                  # task/diffusion.py:255
 
     # ------------------------------------------------------------------ plumbing
@@ -303,14 +304,21 @@ class ClassifierFreeDiffRoll(nn.Module):
         else:
             Tm = T if waveform is None else min(T, waveform.shape[-1] // eng.hop_length + 1)
             spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
-        x = x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        # the chain runs in place on an engine-lifetime buffer so that the captured hipGraph (which
+        # bakes device pointers) is replayed, not re-captured, when the same shape comes again
+        xb = self._xbuf.get((B, Tm))
+        if xb is None:
+            xb = self._xbuf[(B, Tm)] = torch.empty(B, Tm, 88, device=eng.device, dtype=torch.float32)
+        xb.copy_(x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :])
         z = None
         if noise is not None:
             S = self.hparams.timesteps
-            z = noise.to(eng.device, torch.float32).reshape(S, B, T, 88)[:, :, :Tm, :].contiguous()
+            z = noise.to(eng.device, torch.float32).reshape(S, B, T, 88)
+            if Tm != T or not z.is_contiguous():
+                z = z[:, :, :Tm, :].contiguous()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0") else 0.0
-        eng.sample(sampler, x, z, w, seed, first_sample, use_graph)
-        return x.unsqueeze(1), spec
+        eng.sample(sampler, xb, z, w, seed, first_sample, use_graph)
+        return xb.clone().unsqueeze(1), spec
 
     def predict_step(self, batch, batch_idx=0):
         """batch = (x_T, waveform[, ...]) as built by sampling.py:27-46.  Returns the final roll
