@@ -194,8 +194,11 @@ int pick_ni(int taps, int dil) {
 }
 
 // common GemmArgs for a P4 activation input [NB][planes][T][4]
+const float* g_zero_vec = nullptr;   // device zero vector shared by every engine of the process
+
 GemmArgs p4_gemm(const float* Wp, const float* bias, int MT, const float* X, int planes, int NB, int T) {
     GemmArgs a{};
+    a.dvec = g_zero_vec;
     a.Wp = Wp; a.bias = bias; a.MT = MT;
     a.X = X; a.x_bs = (long)planes * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4; a.x_planes = planes;
     a.kchunks = (planes + 7) / 8;
@@ -235,6 +238,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.Wp = e->in_w; a.bias = e->in_b; a.MT = (Cp + 127) / 128;
         a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
         a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+        a.dvec = g_zero_vec;
         p4_out(a, e->h, P, T, Cp);
         HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
     }
@@ -340,6 +344,15 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
         hipError_t ie = init_kernels();
         if (ie != hipSuccess) return fail(nullptr, DR_EHIP, "kernel init failed: %s", hipGetErrorString(ie));
     }
+    if (!g_zero_vec) {
+        void* z = nullptr;
+        const size_t zn = 1 << 16;   // floats; covers every Cin on the path (n_fft, bins, channels)
+        if (hipMalloc(&z, zn * sizeof(float)) != hipSuccess || hipMemset(z, 0, zn * sizeof(float)) != hipSuccess)
+            return fail(nullptr, DR_EHIP, "allocating the zero vector failed");
+        g_zero_vec = (const float*)z;
+    }
+    if (cfg->n_fft > (1 << 16) || cfg->residual_channels > (1 << 15))
+        return fail(nullptr, DR_EINVAL, "configuration too large");
     dr_engine* e = new dr_engine();
     e->cfg = *cfg;
     e->C = cfg->residual_channels;
@@ -624,6 +637,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
         a.Wp = e->dft_w; a.MT = bp / 64;
         a.X = e->wav_pad; a.x_bs = Lp; a.x_ps = 4; a.x_fs = hop; a.x_planes = N / 4; a.kchunks = N / 32;
         a.NB = B; a.T = TF; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+        a.dvec = g_zero_vec;
         p4_out(a, e->power, bp / 4, TF, bp);
         HIPCHK(e, launch_gemm(a, EPI_POWER, 2, st));
     }

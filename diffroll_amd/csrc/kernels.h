@@ -44,7 +44,8 @@ struct GemmArgs {
     long x_bs, x_ps, x_fs;   // batch / plane / frame strides in floats
     int x_planes;            // valid planes (Cin/4); planes beyond read as zero
     int x_bmod;              // sample index is taken modulo this (0 = no modulo)
-    const float* dvec;       // [Cin] added to every valid in-range frame before zero padding (may be null)
+    const float* dvec;       // [>= 4*x_planes] added to every valid in-range frame before zero padding; never
+                             // null: pass a zero vector when there is nothing to add (keeps the loader branch-free)
     int NB, T;               // samples, frames per sample
     int taps, dil;           // conv taps (odd) and dilation; halo = (taps-1)/2*dil
     int kchunks;             // ceil(Cin/32)

@@ -14,11 +14,16 @@
 // Written for wave64 / 4 waves per workgroup; no other target is supported.
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace dr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DR_DEVINL __device__ __forceinline__
+
+struct W4 { float4 v[4]; };
+struct X8 { float4 v[8]; };
 
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -70,82 +75,111 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
+    // Staging of the X tile is branch-free: every thread always loads from a clamped (valid) address
+    // and the value is selected afterwards, so hipcc keeps all loads of a step in flight behind the
+    // MFMAs instead of wrapping each one in a branch + s_waitcnt vmcnt(0).
     const int tx = t0 - halo + tid;                 // frame this thread stages
     const bool xin = (tid < FW) && (tx >= 0) && (tx < a.T);
-    const float* Xt = Xg + (long)tx * a.x_fs;
+    const int txc = min(max(tx, 0), a.T - 1);
+    const float* Xt = Xg + (long)txc * a.x_fs;
+    const int last_plane = a.x_planes - 1;
 
-    float4 xr[8];
-    float4 wreg[4];
-
-    auto load_x = [&](int kc) {
+    // staging registers are passed BY VALUE in plain structs: closure-captured array references defeat
+    // hipcc's scalar replacement and send the prefetch through scratch (+ an early vmcnt wait)
+    auto load_x = [&](int kc) -> X8 {
+        X8 o;
 #pragma unroll
         for (int pl = 0; pl < 8; ++pl) {
             const int plane = kc * 8 + pl;
-            float4 v = f4zero();
-            if (xin && plane < a.x_planes) {
-                v = *reinterpret_cast<const float4*>(Xt + (long)plane * a.x_ps);
-                if (a.dvec) {
-                    const float4 d = *reinterpret_cast<const float4*>(a.dvec + plane * 4);
-                    v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
-                }
-            }
-            xr[pl] = v;
+            const int pc = min(plane, last_plane);
+            float4 v = *reinterpret_cast<const float4*>(Xt + (long)pc * a.x_ps);
+            const float4 d = *reinterpret_cast<const float4*>(a.dvec + pc * 4);
+            const bool ok = xin && (plane <= last_plane);
+            v.x = ok ? v.x + d.x : 0.f;
+            v.y = ok ? v.y + d.y : 0.f;
+            v.z = ok ? v.z + d.z : 0.f;
+            v.w = ok ? v.w + d.w : 0.f;
+            o.v[pl] = v;
         }
+        return o;
     };
-    auto store_x = [&](int buf) {
+    auto store_x = [&](int buf, const X8 xr) {
         if (tid < FW) {
 #pragma unroll
-            for (int pl = 0; pl < 8; ++pl) Xs[(buf * 8 + pl) * FW + tid] = xr[pl];
+            for (int pl = 0; pl < 8; ++pl) Xs[(buf * 8 + pl) * FW + tid] = xr.v[pl];
         }
     };
-    auto load_w = [&](int s) {
+    auto load_w = [&](int s) -> W4 {
+        W4 o;
         const float4* src = Wg + (long)s * 1024 + tid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wreg[i] = src[i * 256];
+        for (int i = 0; i < 4; ++i) o.v[i] = src[i * 256];
+        return o;
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, const W4 wreg) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Ws[buf * 1024 + i * 256 + tid] = wreg[i];
+        for (int i = 0; i < 4; ++i) Ws[buf * 1024 + i * 256 + tid] = wreg.v[i];
     };
 
-    load_x(0);
-    load_w(0);
-    store_x(0);
-    store_w(0);
+    store_x(0, load_x(0));
+    store_w(0, load_w(0));
     __syncthreads();
 
     const int cen = (a.taps - 1) >> 1;
-    int kc = 0, j = 0;
-    for (int s = 0; s < NS; ++s) {
-        const bool more = (s + 1 < NS);
-        const bool newx = more && (j == a.taps - 1);
-        if (more) load_w(s + 1);
-        if (newx) load_x(kc + 1);
+
+    // One K step = one tap of one 32-channel chunk: 64*NI MFMAs per wave.  PFW / PFX (compile time)
+    // say whether the next W slab / the next chunk's X tile are prefetched into registers before the
+    // MFMAs and written to the other LDS buffer after them.  Fragment reads are software-pipelined one
+    // 8-channel group ahead of the MFMAs that consume them.
+    auto step = [&](auto PFW, auto PFX, int s, int kc, int j) {
+        W4 wreg;
+        X8 xr;
+        if constexpr (decltype(PFW)::value) wreg = load_w(s + 1);
+        if constexpr (decltype(PFX)::value) xr = load_x(kc + 1);
+        // keep the prefetch loads issued HERE, ahead of the MFMA block (hipcc otherwise sinks them to
+        // their ds_write and exposes the whole L2/HBM latency once per step)
+        __builtin_amdgcn_sched_barrier(0);
 
         const float4* Xb = Xs + (kc & 1) * 8 * FW + hi * FW + halo + (j - cen) * a.dil + wc * WN + r;
         const float4* Wb = Ws + (s & 1) * 1024 + hi * 128 + wr * 64 + r;
+        float4 af[2][2], bf[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) af[0][mi] = Wb[mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = Xb[ni * 32];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 af[2], bf[NI];
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g < 3) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = Wb[g * 256 + mi * 32];
+                for (int mi = 0; mi < 2; ++mi) af[nxt][mi] = Wb[(g + 1) * 256 + mi * 32];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[ni] = Xb[g * 2 * FW + ni * 32];
+                for (int ni = 0; ni < NI; ++ni) bf[nxt][ni] = Xb[(g + 1) * 2 * FW + ni * 32];
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].x, bf[cur][ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].y, bf[cur][ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].z, bf[cur][ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].w, bf[cur][ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
 
-        if (more) store_w((s + 1) & 1);
-        if (newx) store_x((kc + 1) & 1);
-        __syncthreads();
-        if (++j == a.taps) { j = 0; ++kc; }
+        if constexpr (decltype(PFW)::value) store_w((s + 1) & 1, wreg);
+        if constexpr (decltype(PFX)::value) store_x((kc + 1) & 1, xr);
+        if constexpr (decltype(PFW)::value) __syncthreads();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    int s = 0;
+    for (int kc = 0; kc < a.kchunks; ++kc) {
+        for (int j = 0; j < a.taps - 1; ++j, ++s) step(T_{}, F_{}, s, kc, j);
+        if (kc + 1 < a.kchunks) step(T_{}, T_{}, s, kc, a.taps - 1);
+        else step(F_{}, F_{}, s, kc, a.taps - 1);
+        ++s;
     }
 
     // ----------------------------------------------------------------------------------------
