@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdiffroll_amd.so")
+LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
 DR_ABI_VERSION = 1
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
@@ -26,7 +26,7 @@ COND_SPEC, COND_UNCOND = 0, 1
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
     "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_profile_enable",
-    "dr_profile_read", "dr_bench_layer",
+    "dr_profile_read", "dr_bench_layer", "dr_debug_ticks",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]
     lib.dr_bench_layer.restype = C.c_int
     lib.dr_bench_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.dr_debug_ticks.restype = C.c_int
+    lib.dr_debug_ticks.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     if lib.dr_abi_version() != DR_ABI_VERSION:
         raise RuntimeError("libdiffroll_amd.so ABI version mismatch: rebuild it")
     _lib = lib

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -76,6 +77,7 @@ struct dr_engine {
     GraphKey gkey;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    long long* dbg_ticks = nullptr;     // dr_bench_layer measurement hook
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
 
     // profiling of the dominant kernel
@@ -190,6 +192,8 @@ size_t expected_numel(const dr_engine* e, const std::string& name) {
 
 int pick_ni(int taps, int dil) {
     const int halo = ((taps - 1) / 2) * dil;
+    static const int forced = getenv("DR_CONV_NI") ? atoi(getenv("DR_CONV_NI")) : 0;   // tuning experiments
+    if (forced == 1 || (forced == 2 && 128 + 2 * halo <= 256)) return forced;
     return (128 + 2 * halo <= 256) ? 2 : 1;
 }
 
@@ -384,6 +388,7 @@ void dr_destroy(dr_engine* e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->g, e->skip, e->tmp, e->x0buf, e->cond,
@@ -777,7 +782,24 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     a.c_bs = (long)2 * Cp * T;
     a.n_cond = n_cond;
     p4_out(a, e->g, P, T, Cp);
+    if (!e->dbg_ticks) {
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, 2 * sizeof(long long)));
+        HIPCHK(e, hipMemset(q, 0, 2 * sizeof(long long)));
+        e->dbg_ticks = (long long*)q;
+    }
+    a.dbg = e->dbg_ticks;
     HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(e->K, w.dil), (hipStream_t)stream));
+    return DR_OK;
+}
+
+int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks) {
+    if (!e || !e->dbg_ticks) return fail(e, DR_ESTATE, "no dr_bench_layer launch yet");
+    long long h[2];
+    HIPCHK(e, hipDeviceSynchronize());
+    HIPCHK(e, hipMemcpy(h, e->dbg_ticks, sizeof h, hipMemcpyDeviceToHost));
+    if (loop_ticks) *loop_ticks = h[0];
+    if (block_ticks) *block_ticks = h[1];
     return DR_OK;
 }
 

@@ -62,12 +62,13 @@ struct GemmArgs {
     long s_bs;
     int skip_init;           // 1: skip = value, 0: skip += value
     float alpha;
+    long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
 };
 
 // NI = N sub-tiles of 32 frames per wave: block tile = 128 rows x (64*NI) frames, 256 threads.
 hipError_t init_kernels();
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s);
-size_t gemm_lds_bytes(int NI, int taps, int dil);
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil);
 int gemm_max_halo(int NI);
 
 struct UpdateArgs {

@@ -22,38 +22,76 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DR_DEVINL __device__ __forceinline__
 
-struct W4 { float4 v[4]; };
-struct X8 { float4 v[8]; };
+// DR_ABLATE (compile-time, measurement builds only; results are WRONG when non-zero):
+//   1 = no A-fragment prefetch in the K loop
+#ifndef DR_ABLATE
+#define DR_ABLATE 0
+#endif
+
+struct A8 { float4 v[8]; };                          // A fragments of one K step: [group g][row tile mi]
+
+// sched_group_barrier helpers (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read): NV times
+// {GAP MFMAs, 1 VMEM read}, ND times {GAP MFMAs, 1 DS read}, then REM MFMAs.
+template <int MASK, int N>
+DR_DEVINL void sgb() {
+    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+template <int GAP, int NV, int ND, int REM>
+DR_DEVINL void spread_mem() {
+    if constexpr (NV > 0) {
+        sgb<0x8, GAP>();
+        sgb<0x20, 1>();
+        spread_mem<GAP, NV - 1, ND, REM>();
+    } else if constexpr (ND > 0) {
+        sgb<0x8, GAP>();
+        sgb<0x100, 1>();
+        spread_mem<GAP, 0, ND - 1, REM>();
+    } else {
+        sgb<0x8, REM>();
+    }
+}
 
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM kernel.
-//   block = 256 threads = 4 waves as 2 (M) x 2 (N); block tile 128 packed rows x BN = 64*NI frames
-//   wave tile 64 rows (2 MFMA row-tiles: for the paired epilogues the gate/cos tile and the
-//   filter/sin tile of the SAME 32 channels, so pairing is register-local) x 32*NI frames.
-//   K loop: for kchunk (32 input channels; X tile with halo staged once) for tap (W slab 16 KiB):
-//   64*NI MFMAs per wave per step, one __syncthreads per step, register-staged double buffering.
-//   LDS: X tile [2][8 planes][FW = BN + 2*halo][float4]  +  W slab [2][4][2][128][float4].
-//   All fragment reads are conflict-free ds_read_b128 (lane-contiguous 16 B).
+//   block = 512 threads = 8 waves, SPECIALISED (measured with the s_memtime hook: with one wave per
+//   SIMD every non-MFMA instruction cluster in the consumer's in-order stream is exposed - X loads,
+//   select/add VALU, ds_write and the barrier cost 6.7 of 74.6 ticks per MFMA - while instructions of
+//   ANOTHER wave on the same SIMD overlap the 64-cycle MFMAs):
+//     waves 0-3  consumers, one per SIMD, 2 (M) x 2 (N): wave tile 64 rows x 32*NI frames
+//                (2 MFMA row-tiles: for the paired epilogues the gate/cos tile and the filter/sin tile
+//                of the SAME 32 channels, so pairing is register-local).  They only issue MFMAs, the
+//                A-fragment loads and the B-fragment ds_reads.
+//     waves 4-7  producers: stage the X tile of the NEXT chunk (global -> registers -> + step
+//                embedding, zero padding -> LDS) while the consumers compute the current one.
+//   One s_barrier per chunk hands a staged buffer over (double buffered).
+//
+//   A operand (weights): NEVER staged through LDS.  The packed layout is fragment-shaped, so every
+//   consumer wave loads the 8 float4 A-fragments of a K step (4 channel groups x 2 row tiles) straight
+//   from L2 into VGPRs with two fully coalesced 512-B segments per instruction, one step ahead of use
+//   (measured free).  The 128-row weight panel of an M tile is L2-resident: blockIdx % MT pins a
+//   panel to an XCD.
+//   B operand (activations): X tile [KS*8 planes][FW = BN + 2*halo frames][float4] in LDS; all taps of
+//   the dilated conv read it at shifted frame offsets with conflict-free ds_read_b128.
+//   K loop: for chunk (32*KS input channels) for tap for sub-chunk: 64*NI MFMAs per consumer wave.
 // ---------------------------------------------------------------------------------------------
-template <int NI, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+template <int NI, int KS, int EPI>
+__global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 64 * NI;
     constexpr int WN = 32 * NI;
+    constexpr int XP = 8 * KS;      // planes per X tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long tick0 = a.dbg ? clock64() : 0;   // measurement hook (null in production launches)
 
     const int halo = ((a.taps - 1) >> 1) * a.dil;
     const int FW = BN + 2 * halo;
-    float4* Xs = reinterpret_cast<float4*>(smem);   // [2][8][FW]
-    float4* Ws = Xs + 2 * 8 * FW;                   // [2][1024]
+    float4* Xs = reinterpret_cast<float4*>(smem);   // [2][XP][FW]
 
     // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
     // one 128-row weight panel, which then stays resident in that XCD's private L2.
@@ -62,10 +100,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
-    const int bx = a.x_bmod ? (b % a.x_bmod) : b;
-    const float* Xg = a.X + (long)bx * a.x_bs;
-    const int NS = a.kchunks * a.taps;
-    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024;
+    const int NS = a.kchunks * a.taps;              // K steps (32 channels x 1 tap each)
+    const int nchunks = a.kchunks / KS;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - 256;
+        const int bx = a.x_bmod ? (b % a.x_bmod) : b;
+        const float* Xg = a.X + (long)bx * a.x_bs;
+        const int tx = t0 - halo + ptid;                // frame this thread stages
+        const bool xin = (ptid < FW) && (tx >= 0) && (tx < a.T);
+        const int txc = min(max(tx, 0), a.T - 1);       // clamped: loads are unconditional (branch-free)
+        const float* Xt = Xg + (long)txc * a.x_fs;
+        const int last_plane = a.x_planes - 1;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            float4 xv[XP], xd[XP];
+#pragma unroll
+            for (int pl = 0; pl < XP; ++pl) {
+                const int pc = min(chunk * XP + pl, last_plane);
+                xv[pl] = *reinterpret_cast<const float4*>(Xt + (long)pc * a.x_ps);
+                xd[pl] = *reinterpret_cast<const float4*>(a.dvec + pc * 4);
+            }
+            if (ptid < FW) {
+#pragma unroll
+                for (int pl = 0; pl < XP; ++pl) {
+                    // zero padding applies to (h + d): model/diffwave.py:139-144
+                    const bool ok = xin && (chunk * XP + pl <= last_plane);
+                    float4 v = xv[pl];
+                    v.x = ok ? v.x + xd[pl].x : 0.f;
+                    v.y = ok ? v.y + xd[pl].y : 0.f;
+                    v.z = ok ? v.z + xd[pl].z : 0.f;
+                    v.w = ok ? v.w + xd[pl].w : 0.f;
+                    Xs[((chunk & 1) * XP + pl) * FW + ptid] = v;
+                }
+            }
+            __syncthreads();   // hand-over #chunk (the consumers' matching barrier opens their chunk)
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, hi = lane >> 5;
+    // this lane's A fragments inside a 16-KiB slab: [g][hi][row][4]
+    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024 + hi * 128 + wr * 64 + r;
 
     f32x16 acc[2][NI];
 #pragma unroll
@@ -75,76 +153,38 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    // Staging of the X tile is branch-free: every thread always loads from a clamped (valid) address
-    // and the value is selected afterwards, so hipcc keeps all loads of a step in flight behind the
-    // MFMAs instead of wrapping each one in a branch + s_waitcnt vmcnt(0).
-    const int tx = t0 - halo + tid;                 // frame this thread stages
-    const bool xin = (tid < FW) && (tx >= 0) && (tx < a.T);
-    const int txc = min(max(tx, 0), a.T - 1);
-    const float* Xt = Xg + (long)txc * a.x_fs;
-    const int last_plane = a.x_planes - 1;
-
-    // staging registers are passed BY VALUE in plain structs: closure-captured array references defeat
-    // hipcc's scalar replacement and send the prefetch through scratch (+ an early vmcnt wait)
-    auto load_x = [&](int kc) -> X8 {
-        X8 o;
+    auto load_a = [&](int slab) -> A8 {
+        A8 o;
+        const float4* src = Wg + (long)slab * 1024;
 #pragma unroll
-        for (int pl = 0; pl < 8; ++pl) {
-            const int plane = kc * 8 + pl;
-            const int pc = min(plane, last_plane);
-            float4 v = *reinterpret_cast<const float4*>(Xt + (long)pc * a.x_ps);
-            const float4 d = *reinterpret_cast<const float4*>(a.dvec + pc * 4);
-            const bool ok = xin && (plane <= last_plane);
-            v.x = ok ? v.x + d.x : 0.f;
-            v.y = ok ? v.y + d.y : 0.f;
-            v.z = ok ? v.z + d.z : 0.f;
-            v.w = ok ? v.w + d.w : 0.f;
-            o.v[pl] = v;
-        }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) o.v[g * 2 + mi] = src[g * 256 + mi * 32];
         return o;
     };
-    auto store_x = [&](int buf, const X8 xr) {
-        if (tid < FW) {
-#pragma unroll
-            for (int pl = 0; pl < 8; ++pl) Xs[(buf * 8 + pl) * FW + tid] = xr.v[pl];
-        }
-    };
-    auto load_w = [&](int s) -> W4 {
-        W4 o;
-        const float4* src = Wg + (long)s * 1024 + tid;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o.v[i] = src[i * 256];
-        return o;
-    };
-    auto store_w = [&](int buf, const W4 wreg) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Ws[buf * 1024 + i * 256 + tid] = wreg.v[i];
-    };
 
-    store_x(0, load_x(0));
-    store_w(0, load_w(0));
-    __syncthreads();
-
+    A8 wA = load_a(0), wB;
+#if DR_ABLATE >= 1
+    wB = load_a(min(1, NS - 1));
+#endif
     const int cen = (a.taps - 1) >> 1;
 
-    // One K step = one tap of one 32-channel chunk: 64*NI MFMAs per wave.  PFW / PFX (compile time)
-    // say whether the next W slab / the next chunk's X tile are prefetched into registers before the
-    // MFMAs and written to the other LDS buffer after them.  Fragment reads are software-pipelined one
-    // 8-channel group ahead of the MFMAs that consume them.
-    auto step = [&](auto PFW, auto PFX, int s, int kc, int j) {
-        W4 wreg;
-        X8 xr;
-        if constexpr (decltype(PFW)::value) wreg = load_w(s + 1);
-        if constexpr (decltype(PFX)::value) xr = load_x(kc + 1);
+    // One K step: 64*NI MFMAs per wave.  ROLE (compile time) selects which of the two A-fragment
+    // register sets is consumed; the other one receives the next step's fragments (prefetch distance
+    // one step).  Roles alternate statically so there are no per-step register copies.
+    auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
+        constexpr bool kB = decltype(ROLE)::value;
+#if DR_ABLATE == 0
+        if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
+        else wB = load_a(min(slab + 1, NS - 1));
+#endif
         // keep the prefetch loads issued HERE, ahead of the MFMA block (hipcc otherwise sinks them to
-        // their ds_write and exposes the whole L2/HBM latency once per step)
+        // their first use and exposes the whole L2 latency once per step).  Spreading them through the
+        // MFMA stream with sched_group_barrier was measured slower (317 vs 300 us per launch).
         __builtin_amdgcn_sched_barrier(0);
 
-        const float4* Xb = Xs + (kc & 1) * 8 * FW + hi * FW + halo + (j - cen) * a.dil + wc * WN + r;
-        const float4* Wb = Ws + (s & 1) * 1024 + hi * 128 + wr * 64 + r;
-        float4 af[2][2], bf[2][NI];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) af[0][mi] = Wb[mi * 32];
+        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WN + r;
+        float4 bf[2][NI];
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bf[0][ni] = Xb[ni * 32];
 #pragma unroll
@@ -152,36 +192,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
             const int cur = g & 1, nxt = cur ^ 1;
             if (g < 3) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) af[nxt][mi] = Wb[(g + 1) * 256 + mi * 32];
-#pragma unroll
                 for (int ni = 0; ni < NI; ++ni) bf[nxt][ni] = Xb[(g + 1) * 2 * FW + ni * 32];
             }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].x, bf[cur][ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].y, bf[cur][ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].z, bf[cur][ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][mi].w, bf[cur][ni].w, acc[mi][ni], 0, 0, 0);
+                    const float4 af = kB ? wB.v[g * 2 + mi] : wA.v[g * 2 + mi];
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[cur][ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[cur][ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[cur][ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[cur][ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-
-        if constexpr (decltype(PFW)::value) store_w((s + 1) & 1, wreg);
-        if constexpr (decltype(PFX)::value) store_x((kc + 1) & 1, xr);
-        if constexpr (decltype(PFW)::value) __syncthreads();
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-    int s = 0;
-    for (int kc = 0; kc < a.kchunks; ++kc) {
-        for (int j = 0; j < a.taps - 1; ++j, ++s) step(T_{}, F_{}, s, kc, j);
-        if (kc + 1 < a.kchunks) step(T_{}, T_{}, s, kc, a.taps - 1);
-        else step(F_{}, F_{}, s, kc, a.taps - 1);
-        ++s;
+    // Steps of a chunk, q = 0 .. per_chunk-1, in memory order of the slabs ([32-channel kchunk][tap]):
+    // tap-major, sub-chunk minor.  Roles alternate A,B,A,...; a chunk always starts in role A (one
+    // register copy per chunk when per_chunk is odd).
+    const int per_chunk = a.taps * KS;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        auto at = [&](auto R, int q) {
+            const int j = q / KS, sub = q - j * KS;
+            step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+        };
+        __syncthreads();   // X tile #chunk staged by the producers (matches their hand-over barrier)
+        int q = 0;
+        for (; q + 2 <= per_chunk; q += 2) {
+            at(F_{}, q);
+            at(T_{}, q + 1);
+        }
+        if (q < per_chunk) {
+            at(F_{}, q);
+#if DR_ABLATE == 0
+            wA = wB;
+#endif
+        }
     }
 
+    const long long tick1 = a.dbg ? clock64() : 0;
     // ----------------------------------------------------------------------------------------
     // epilogue.  C/D fragment of 32x32: column = lane&31 (frame), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
@@ -277,70 +328,76 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
             }
         }
     }
+    if (a.dbg && blockIdx.x == 0 && tid == 0) {
+        a.dbg[0] = tick1 - tick0;           // main loop
+        a.dbg[1] = clock64() - tick0;       // whole block
+    }
 }
 
-size_t gemm_lds_bytes(int NI, int taps, int dil) {
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil) {
     const int halo = ((taps - 1) / 2) * dil;
     const int FW = 64 * NI + 2 * halo;
-    return (size_t)2 * 8 * FW * 16 + (size_t)2 * 16384;
+    return (size_t)2 * 8 * KS * FW * 16;
 }
 int gemm_max_halo(int NI) { return (256 - 64 * NI) / 2; }
 
-template <int NI, int EPI>
+template <int NI, int KS, int EPI>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 64 * NI;
     const int tps = (a.T + BN - 1) / BN;
-    const size_t lds = gemm_lds_bytes(NI, a.taps, a.dil);
+    const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil);
     const dim3 grid((unsigned)(a.MT * a.NB * tps));
-    hipLaunchKernelGGL((gemm_kernel<NI, EPI>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI>), grid, dim3(512), lds, s, a);
     return hipGetLastError();
 }
 
-template <int NI, int EPI>
+template <int NI, int KS, int EPI>
 static hipError_t init_gemm_t() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NI, EPI>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NI, KS, EPI>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
-template <int NI>
+template <int NI, int KS>
 static hipError_t init_gemm_ni() {
     hipError_t e;
-    if ((e = init_gemm_t<NI, EPI_PLAIN>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, EPI_RELU>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, EPI_SILU>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, EPI_GATE>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, EPI_RES_SKIP>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, EPI_POWER>()) != hipSuccess) return e;
-    return init_gemm_t<NI, EPI_LOG>();
+    if ((e = init_gemm_t<NI, KS, EPI_PLAIN>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_RELU>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_SILU>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_GATE>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_RES_SKIP>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_POWER>()) != hipSuccess) return e;
+    return init_gemm_t<NI, KS, EPI_LOG>();
 }
 // allow > 64 KiB of dynamic LDS for every instantiation; call once per process before any launch
 // (and never inside a stream capture)
 hipError_t init_kernels() {
-    hipError_t e = init_gemm_ni<1>();
-    if (e != hipSuccess) return e;
-    return init_gemm_ni<2>();
+    hipError_t e;
+    if ((e = init_gemm_ni<1, 1>()) != hipSuccess) return e;
+    if ((e = init_gemm_ni<2, 1>()) != hipSuccess) return e;
+    if ((e = init_gemm_ni<1, 2>()) != hipSuccess) return e;
+    return init_gemm_ni<2, 2>();
 }
 
-template <int NI>
+template <int NI, int KS>
 static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_PLAIN: return launch_gemm_t<NI, EPI_PLAIN>(a, s);
-        case EPI_RELU: return launch_gemm_t<NI, EPI_RELU>(a, s);
-        case EPI_SILU: return launch_gemm_t<NI, EPI_SILU>(a, s);
-        case EPI_GATE: return launch_gemm_t<NI, EPI_GATE>(a, s);
-        case EPI_RES_SKIP: return launch_gemm_t<NI, EPI_RES_SKIP>(a, s);
-        case EPI_POWER: return launch_gemm_t<NI, EPI_POWER>(a, s);
-        case EPI_LOG: return launch_gemm_t<NI, EPI_LOG>(a, s);
+        case EPI_PLAIN: return launch_gemm_t<NI, KS, EPI_PLAIN>(a, s);
+        case EPI_RELU: return launch_gemm_t<NI, KS, EPI_RELU>(a, s);
+        case EPI_SILU: return launch_gemm_t<NI, KS, EPI_SILU>(a, s);
+        case EPI_GATE: return launch_gemm_t<NI, KS, EPI_GATE>(a, s);
+        case EPI_RES_SKIP: return launch_gemm_t<NI, KS, EPI_RES_SKIP>(a, s);
+        case EPI_POWER: return launch_gemm_t<NI, KS, EPI_POWER>(a, s);
+        case EPI_LOG: return launch_gemm_t<NI, KS, EPI_LOG>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s) {
     const int halo = ((a.taps - 1) / 2) * a.dil;
-    if (64 * NI + 2 * halo > 256) return hipErrorInvalidValue;
-    switch (NI) {
-        case 1: return launch_gemm_ni<1>(a, epi, s);
-        case 2: return launch_gemm_ni<2>(a, epi, s);
-    }
+    if (64 * NI + 2 * halo > 256 || a.kchunks < 1) return hipErrorInvalidValue;
+    // 1x1 GEMMs restage X every step: take 64 channels per chunk there (half the barriers)
+    const int KS = (a.taps == 1 && a.kchunks % 2 == 0) ? 2 : 1;
+    if (NI == 1) return KS == 2 ? launch_gemm_ni<1, 2>(a, epi, s) : launch_gemm_ni<1, 1>(a, epi, s);
+    if (NI == 2) return KS == 2 ? launch_gemm_ni<2, 2>(a, epi, s) : launch_gemm_ni<2, 1>(a, epi, s);
     return hipErrorInvalidValue;
 }
 

@@ -174,6 +174,12 @@ class Engine:
         self._check(self.lib.dr_profile_read(self.h, C.byref(n), C.byref(ms), 1 if reset else 0))
         return n.value, ms.value
 
+    def debug_ticks(self) -> Tuple[int, int]:
+        a = C.c_int64(0)
+        b = C.c_int64(0)
+        self._check(self.lib.dr_debug_ticks(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def bench_layer(self, layer: int, NB: int, T: int, t: int, n_cond: int):
         with torch.cuda.device(self.device):
             self._check(self.lib.dr_bench_layer(self.h, layer, NB, T, t, n_cond, self._stream()))
