@@ -1,0 +1,76 @@
+"""CPU-only checks of the C-ABI boundary: the library builds, loads, and exports exactly the symbols
+include/diffroll_amd.h declares; without a GPU every entry point fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from diffroll_amd.build import build
+    from diffroll_amd import _cabi
+    build(verbose=False)
+    return _cabi.load_library()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dr_[a-z_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    from diffroll_amd import _cabi
+    declared = header_functions()
+    assert declared, "no functions parsed from the header"
+    assert sorted(_cabi.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_abi_version(lib):
+    from diffroll_amd import _cabi
+    assert lib.dr_abi_version() == _cabi.DR_ABI_VERSION
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    assert int(re.search(r"#define DR_ABI_VERSION (\d+)", text).group(1)) == _cabi.DR_ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    from diffroll_amd import _cabi
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    body = re.search(r"typedef struct dr_config \{(.*?)\} dr_config;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(int32_t|float)\s+(\w+);", body)
+    assert [f[1] for f in fields] == [f[0] for f in _cabi.DrConfig._fields_]
+    for (ctype, _), (_, pyt) in zip(fields, _cabi.DrConfig._fields_):
+        assert pyt is (C.c_int32 if ctype == "int32_t" else C.c_float)
+    assert C.sizeof(_cabi.DrConfig) == 4 * len(fields)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly(lib):
+    from diffroll_amd import _cabi
+    cfg = _cabi.DrConfig(abi_version=_cabi.DR_ABI_VERSION, device=0, residual_channels=64, residual_layers=2,
+                         kernel_size=3, dilation_base=2, dilation_bound=4, n_mels=229, timesteps=8,
+                         sample_rate=16000, n_fft=2048, hop_length=512, f_min=0.0, f_max=8000.0,
+                         beta_start=1e-4, beta_end=0.02)
+    h = C.c_void_p()
+    rc = lib.dr_create(C.byref(h), C.byref(cfg))
+    assert rc == _cabi.DR_EHIP and not h.value
+    assert b"no CPU fallback" in lib.dr_last_error(None)
+    # wrong ABI version / bad config are rejected before touching the device
+    cfg.abi_version = 999
+    assert lib.dr_create(C.byref(h), C.byref(cfg)) == _cabi.DR_EINVAL
+    # python wrapper raises
+    from diffroll_amd import ClassifierFreeDiffRoll, EngineError
+    m = ClassifierFreeDiffRoll(64, False, "fixed", 229, [0, 1, "imagewise"], residual_layers=2, kernel_size=3,
+                               dilation_base=2, sampling={"type": "cfdg_ddpm_x0", "w": 0.5})
+    with pytest.raises(EngineError):
+        m.engine
+    with pytest.raises(EngineError):
+        m(torch.zeros(1, 1, 8, 88), torch.zeros(1, 4096), torch.zeros(1, dtype=torch.long))

@@ -1,0 +1,116 @@
+"""CPU-only checks of the host-side logic of the product (diffroll_amd): constant tables against the
+reference-generated golden vectors and the oracle, façade surface / error behaviour, shard arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffroll_ref as R
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("S", [50, 200])
+def test_schedule_and_embedding_bit_equal_to_reference(golden_dir, S):
+    from diffroll_amd.schedule import build_embedding, make_schedule
+    g = load(golden_dir, f"schedule_{S}")
+    sch = make_schedule(1e-4, 0.02, S)
+    for k in ("betas", "alphas", "sqrt_recip_alphas", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "posterior_variance"):
+        assert np.array_equal(sch[k].numpy(), g[k]), k
+    assert np.array_equal(build_embedding(S).numpy(), g["embedding"])
+
+
+def test_posterior_coef_table_reproduces_the_update():
+    """Feeding the (S,5) table through the kernel's formula equals the oracle's posterior_update
+    (task/diffusion.py:957-967) bit for bit on CPU."""
+    from diffroll_amd.schedule import make_schedule, posterior_coef_table
+    S = 200
+    sch = make_schedule(1e-4, 0.02, S)
+    coef = posterior_coef_table(sch)
+    osch = R.schedule(1e-4, 0.02, S)
+    torch.manual_seed(0)
+    x, x0, z = torch.randn(3, 1, 7, 88), torch.randn(3, 1, 7, 88), torch.randn(3, 1, 7, 88)
+    for t in (S - 1, 100, 1, 0):
+        ref = R.posterior_update(osch, x, x0, t, z)
+        c = coef[t]
+        if t == 0:
+            mine = x0 / c[2]
+        else:
+            mine = (c[0] * x0 + (c[1] * (x - c[2] * x0)) / c[3]) + c[4] * z
+        assert torch.equal(mine, ref), t
+
+
+def make(**kw):
+    from diffroll_amd import ClassifierFreeDiffRoll
+    args = dict(residual_channels=32, unconditional=False, condition="fixed", n_mels=229,
+                norm_args=[0, 1, "imagewise"], residual_layers=3, kernel_size=9, dilation_base=2,
+                dilation_bound=4, spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229,
+                                                 f_min=0, f_max=8000, center=True, normalized=True,
+                                                 pad_mode="reflect"),
+                spec_dropout=0.1, timesteps=8, sampling={"type": "cfdg_ddpm_x0", "w": 0.5},
+                training={"mode": "x_0"})
+    args.update(kw)
+    return ClassifierFreeDiffRoll(**args)
+
+
+def test_state_dict_names_and_shapes_match_the_reference_layout():
+    m = make()
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=32, residual_layers=3, kernel_size=9, timesteps=8)
+    ref = R.synthetic_params(hp, seed=0)          # names/shapes as in SURVEY.md 8b
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    m.load_state_dict({**ref, "mel_layer.spectrogram.window": torch.zeros(2048)})   # extra mel buffers tolerated
+    assert torch.equal(m.state_dict()["skip_projection.weight"], ref["skip_projection.weight"])
+    # reference zero-initialises the output projection (model/diffwave.py:630)
+    assert float(make().output_projection.weight.abs().sum()) == 0.0
+
+
+def test_hparams_and_error_behaviour():
+    m = make(inpainting_t=[3, 6])
+    assert m.hparams.sampling.w == 0.5 and m.hparams.sampling.type == "cfdg_ddpm_x0"
+    assert m.hparams.timesteps == 8 and m.hparams.inpainting_t == [3, 6]
+    assert m.hparams.spec_args.hop_length == 512 and m.hparams.training.mode == "x_0"
+    assert m.reverse_diffusion.__func__ is type(m).cfdg_ddpm_x0
+    assert m.betas.shape == (8,) and m.sqrt_alphas_cumprod.shape == (8,)
+    with pytest.raises(ValueError):
+        make(condition="bogus")                      # model/diffwave.py:610
+    with pytest.raises(NotImplementedError):
+        make(condition="trainable_z")
+    with pytest.raises(AttributeError):
+        make(sampling={"type": "no_such_sampler"})   # getattr at task/diffusion.py:255
+    with pytest.raises(NotImplementedError):
+        make(sampling={"type": "ddim_x0"})
+    for s in ("ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0"):
+        assert make(sampling={"type": s, "w": 0.1}).reverse_diffusion is not None
+
+
+def test_mask_ranges_follow_python_slicing():
+    from diffroll_amd.engine import _clamp_range
+    n = 41
+    base = list(range(n))
+    for r in ([4, 9], [0, 100], [-5, 3], [30, 10], [-10, -2], [50, 60], None, []):
+        lo, hi = _clamp_range(r, n)
+        if not r:
+            assert (lo, hi) == (-1, -1)
+        else:
+            assert base[lo:hi] == base[int(r[0]):int(r[1])], r
+
+
+def test_shard_bounds_partition():
+    from diffroll_amd.distributed import shard_bounds
+    for n in (1, 7, 16, 128, 129):
+        for ws in (1, 2, 3, 8):
+            seen = []
+            for r in range(ws):
+                lo, hi = shard_bounds(n, r, ws)
+                assert 0 <= lo <= hi <= n and hi - lo in (n // ws, n // ws + 1)
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
