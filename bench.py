@@ -60,6 +60,17 @@ def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0):
     return m
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); counters
+    cannot be collected live from inside the timed process, so this is the per-round profile value."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(model, budget_s=12.0, max_steps=6):
     """The oracle (CPU port of the reference arithmetic) on this box's host cores, bounded sample."""
     from oracle import diffroll_ref as R           # checker / baseline only - never the product path
@@ -191,7 +202,7 @@ def main():
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm_kernel<2,EPI_GATE> (dilated conv k=9 + conditioner + gate)",
             "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(),
             "launches": launches, "avg_launch_us": round(avg_s * 1e6, 2),
             "flops_per_launch": flops_per_frame * frames_per_launch,
             "share_of_step_time": round((ms * 1e-3) / (dt / args.steps), 4),

@@ -26,7 +26,7 @@ COND_SPEC, COND_UNCOND = 0, 1
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
     "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_profile_enable",
-    "dr_profile_read", "dr_bench_layer", "dr_debug_ticks",
+    "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]
     lib.dr_bench_layer.restype = C.c_int
     lib.dr_bench_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.dr_bench_pointwise.restype = C.c_int
+    lib.dr_bench_pointwise.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.dr_debug_ticks.restype = C.c_int
     lib.dr_debug_ticks.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     if lib.dr_abi_version() != DR_ABI_VERSION:

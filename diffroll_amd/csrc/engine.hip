@@ -64,11 +64,12 @@ struct dr_engine {
 
     // activation workspace (sized for ws_NB samples x ws_T frames)
     int ws_NB = 0, ws_T = 0;
-    float *h = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
+    float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
     // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
     int fe_B = 0, fe_T = 0;
     size_t cond_cap = 0;
     float* cond = nullptr;
+    float* cond_dummy = nullptr;   // one sample of readable memory for generation (no dr_frontend): never used
     // front-end workspace
     size_t fe_cap_wav = 0, fe_cap_pow = 0, fe_cap_log = 0, fe_cap_spec = 0, fe_cap_mm = 0;
     float *wav_pad = nullptr, *power = nullptr, *logmel = nullptr, *specP4 = nullptr, *mm = nullptr;
@@ -202,8 +203,8 @@ const float* g_zero_vec = nullptr;   // device zero vector shared by every engin
 
 GemmArgs p4_gemm(const float* Wp, const float* bias, int MT, const float* X, int planes, int NB, int T) {
     GemmArgs a{};
-    a.dvec = g_zero_vec;
-    a.Wp = Wp; a.bias = bias; a.MT = MT;
+    a.d2 = g_zero_vec;
+    a.Wp = Wp; a.bias = bias ? bias : g_zero_vec; a.MT = MT;
     a.X = X; a.x_bs = (long)planes * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4; a.x_planes = planes;
     a.kchunks = (planes + 7) / 8;
     a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
@@ -219,10 +220,12 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     const size_t act = (size_t)nb * e->Cp * T;
     int rc;
     if ((rc = dev_alloc(e, &e->h, act))) return rc;
+    if ((rc = dev_alloc(e, &e->hd, act))) return rc;
     if ((rc = dev_alloc(e, &e->g, act))) return rc;
     if ((rc = dev_alloc(e, &e->skip, act))) return rc;
     if ((rc = dev_alloc(e, &e->tmp, act))) return rc;
     if ((rc = dev_alloc(e, &e->x0buf, (size_t)nb * T * 88))) return rc;
+    if ((rc = dev_alloc(e, &e->cond_dummy, (size_t)2 * e->Cp * T))) return rc;
     e->ws_NB = nb;
     e->ws_T = T;
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
@@ -242,18 +245,17 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.Wp = e->in_w; a.bias = e->in_b; a.MT = (Cp + 127) / 128;
         a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
         a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
-        a.dvec = g_zero_vec;
         p4_out(a, e->h, P, T, Cp);
+        a.Y2 = e->hd; a.d2 = e->d_dtab + (size_t)t * L * Cp;     // hd = h + d_0 (model/diffwave.py:138-139)
         HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
         {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
-            GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->h, P, NB, T);
+            GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
             a.bias2 = w.conv_b_u;
-            a.dvec = e->d_dtab + ((size_t)t * L + l) * Cp;
             a.taps = e->K; a.dil = w.dil;
-            a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : nullptr;
+            a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
             a.c_bs = (long)2 * Cp * T;
             a.n_cond = n_cond;
             p4_out(a, e->g, P, T, Cp);
@@ -265,20 +267,22 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
             GemmArgs a = p4_gemm(w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
             p4_out(a, e->h, P, T, Cp);
+            if (l + 1 < L) { a.Y2 = e->hd; a.d2 = e->d_dtab + ((size_t)t * L + l + 1) * Cp; }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
-            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, 2, st));
+            static const int ni_1x1 = getenv("DR_1X1_NI") ? atoi(getenv("DR_1X1_NI")) : 2;   // tuning experiments
+            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, ni_1x1, st));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
         GemmArgs a = p4_gemm(e->skip_w, e->skip_b, (Cp + 127) / 128, e->skip, P, NB, T);
         a.alpha = (float)(1.0 / std::sqrt((double)L));
         p4_out(a, e->tmp, P, T, Cp);
-        HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
+        HIPCHK(e, launch_gemm(a, EPI_RELU, 1, st));   // M = C only: 64-frame tiles to fill more CUs
     }
     {   // output projection, written straight into the (B,T,88) roll layout (:685-686)
         GemmArgs a = p4_gemm(e->outp_w, e->outp_b, 1, e->tmp, P, NB, T);
         a.Y = x0_out; a.y_bs = (long)T * 88; a.y_ps = 4; a.y_fs = 88; a.y_rows = 88;
-        HIPCHK(e, launch_gemm(a, EPI_PLAIN, 2, st));
+        HIPCHK(e, launch_gemm(a, EPI_PLAIN, 1, st));  // M = 88 (one row tile): 64-frame tiles
     }
     return DR_OK;
 }
@@ -391,7 +395,7 @@ void dr_destroy(dr_engine* e) {
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
-    float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->g, e->skip, e->tmp, e->x0buf, e->cond,
+    float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
                      e->wav_pad, e->power, e->logmel, e->specP4, e->mm};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
@@ -639,10 +643,10 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     //    (plane stride 4 samples, frame stride hop) - no im2col copy.
     {
         GemmArgs a{};
-        a.Wp = e->dft_w; a.MT = bp / 64;
+        a.Wp = e->dft_w; a.MT = bp / 64; a.bias = g_zero_vec;
         a.X = e->wav_pad; a.x_bs = Lp; a.x_ps = 4; a.x_fs = hop; a.x_planes = N / 4; a.kchunks = N / 32;
         a.NB = B; a.T = TF; a.taps = 1; a.dil = 1; a.alpha = 1.f;
-        a.dvec = g_zero_vec;
+        a.d2 = g_zero_vec;
         p4_out(a, e->power, bp / 4, TF, bp);
         HIPCHK(e, launch_gemm(a, EPI_POWER, 2, st));
     }
@@ -774,18 +778,18 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
     const LayerW& w = e->layers[layer];
-    GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->h, P, NB, T);
+    GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
     a.bias2 = w.conv_b_u;
-    a.dvec = e->d_dtab + ((size_t)t * e->L + layer) * Cp;
     a.taps = e->K; a.dil = w.dil;
-    a.cond = e->cond ? e->cond + (size_t)layer * e->fe_B * 2 * Cp * T : nullptr;
+    (void)t;
+    a.cond = e->cond ? e->cond + (size_t)layer * e->fe_B * 2 * Cp * T : e->cond_dummy;
     a.c_bs = (long)2 * Cp * T;
     a.n_cond = n_cond;
     p4_out(a, e->g, P, T, Cp);
     if (!e->dbg_ticks) {
         void* q = nullptr;
-        HIPCHK(e, hipMalloc(&q, 2 * sizeof(long long)));
-        HIPCHK(e, hipMemset(q, 0, 2 * sizeof(long long)));
+        HIPCHK(e, hipMalloc(&q, 16 * sizeof(long long)));
+        HIPCHK(e, hipMemset(q, 0, 16 * sizeof(long long)));
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
@@ -793,13 +797,41 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     return DR_OK;
 }
 
+int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
+    if (!e) return DR_EINVAL;
+    if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    if (layer < 0 || layer >= e->L) return fail(e, DR_EINVAL, "bad argument");
+    int rc = ensure_workspace(e, NB, T);
+    if (rc) return rc;
+    const int Cp = e->Cp, P = Cp / 4;
+    const LayerW& w = e->layers[layer];
+    GemmArgs a = p4_gemm(w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+    p4_out(a, e->h, P, T, Cp);
+    a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = 0;
+    if (!e->dbg_ticks) {
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, 16 * sizeof(long long)));
+        HIPCHK(e, hipMemset(q, 0, 16 * sizeof(long long)));
+        e->dbg_ticks = (long long*)q;
+    }
+    a.dbg = e->dbg_ticks;
+    static const int ni_1x1 = getenv("DR_1X1_NI") ? atoi(getenv("DR_1X1_NI")) : 2;
+    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, ni_1x1, (hipStream_t)stream));
+    return DR_OK;
+}
+
 int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks) {
     if (!e || !e->dbg_ticks) return fail(e, DR_ESTATE, "no dr_bench_layer launch yet");
-    long long h[2];
+    long long h[16];
     HIPCHK(e, hipDeviceSynchronize());
     HIPCHK(e, hipMemcpy(h, e->dbg_ticks, sizeof h, hipMemcpyDeviceToHost));
     if (loop_ticks) *loop_ticks = h[0];
     if (block_ticks) *block_ticks = h[1];
+    if (getenv("DR_DEBUG_CHUNKS")) {
+        fprintf(stderr, "[dr] chunk-start ticks since block start:");
+        for (int i = 2; i < 16; ++i) fprintf(stderr, " %lld", h[i]);
+        fprintf(stderr, "\n");
+    }
     return DR_OK;
 }
 

@@ -37,15 +37,13 @@ enum Epilogue : int {
 struct GemmArgs {
     // A operand
     const float* Wp;      // packed weights
-    const float* bias;    // [MT*128] in packed-row order (may be null)
+    const float* bias;    // [MT*128] in packed-row order; never null (pass a zero vector: loads are unconditional)
     const float* bias2;   // EPI_GATE: bias for samples >= n_cond (unconditional: conv bias + cond const)
     // B operand
     const float* X;
     long x_bs, x_ps, x_fs;   // batch / plane / frame strides in floats
-    int x_planes;            // valid planes (Cin/4); planes beyond read as zero
+    int x_planes;            // valid planes (Cin/4); planes beyond re-read the last one (their weights are zero)
     int x_bmod;              // sample index is taken modulo this (0 = no modulo)
-    const float* dvec;       // [>= 4*x_planes] added to every valid in-range frame before zero padding; never
-                             // null: pass a zero vector when there is nothing to add (keeps the loader branch-free)
     int NB, T;               // samples, frames per sample
     int taps, dil;           // conv taps (odd) and dilation; halo = (taps-1)/2*dil
     int kchunks;             // ceil(Cin/32)
@@ -53,15 +51,20 @@ struct GemmArgs {
     // output
     float* Y;
     long y_bs, y_ps, y_fs;
+    float* Y2;               // EPI_RELU / residual rows of EPI_RES_SKIP: optional second output Y2 = Y + d2[row]
+                             // (same strides): the (h + step embedding) tensor the next dilated conv reads
+    const float* d2;         // [>= y_rows] never null (zero vector when unused)
     int y_rows;              // valid output rows (quads starting at >= y_rows are not written)
     // epilogue extras
-    const float* cond;       // EPI_GATE: [n_cond][MT*32 planes][T][4] in packed-row order
+    const float* cond;       // EPI_GATE: [n_cond][MT*32 planes][T][4] in packed-row order; must point at valid memory
+                             // of at least one sample even when n_cond == 0 (prefetched unconditionally, then ignored)
     long c_bs;
     int n_cond;
     float* skip;             // EPI_RES_SKIP: P4 [NB][MT/2*32 planes][T][4]
     long s_bs;
     int skip_init;           // 1: skip = value, 0: skip += value
     float alpha;
+    int xcd_n;               // set by the launcher: block -> (M tile, frame tile) mapping, see gemm_kernel
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
 };
 

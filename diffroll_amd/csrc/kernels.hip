@@ -19,11 +19,12 @@
 namespace dr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DR_DEVINL __device__ __forceinline__
 
 // DR_ABLATE (compile-time, measurement builds only; results are WRONG when non-zero):
-//   1 = no A-fragment prefetch in the K loop
+//   1 = no A-fragment prefetch in the K loop, 9 = producers do no loads / LDS writes (barriers only)
 #ifndef DR_ABLATE
 #define DR_ABLATE 0
 #endif
@@ -95,8 +96,18 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 
     // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
     // one 128-row weight panel, which then stays resident in that XCD's private L2.
-    const int mt = blockIdx.x % a.MT;
-    const int nt = blockIdx.x / a.MT;
+    // xcd_n != 0 (X-heavy 1x1 GEMMs: small weights, big activations): the 8 M tiles of one frame tile
+    // run on the SAME XCD instead, so the X tile is fetched from HBM once per XCD and hits L2 for the
+    // other M tiles, while the (small) weight matrix is L2-resident in every XCD.
+    int mt, nt;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        nt = (idx / a.MT) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        nt = blockIdx.x / a.MT;
+    }
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
@@ -104,37 +115,46 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     const int nchunks = a.kchunks / KS;
 
     if (wave >= 4) {
-        // ------------------------------------------------------------------ producers
-        const int ptid = tid - 256;
+        // ------------------------------------------------------------------ producers (LDS-DMA)
+        // Each X-tile plane row (FW float4 = frames t0-halo .. t0+BN+halo-1 of 4 channels) is copied
+        // global -> LDS by ceil(FW/64) `buffer_load_dwordx4 ... lds` instructions (64 lanes x 16 B, LDS
+        // destination = wave-uniform base + lane*16).  The buffer descriptor covers exactly frames
+        // [0, T) of that plane, so frames outside the clip - the conv's zero padding and the tail of the
+        // last tile - come back as 0 from the hardware bounds check: no VALU, no ds_write, no VGPR
+        // staging.  Producers therefore issue a handful of instructions per chunk and no longer steal
+        // issue slots from the consumers' MFMA stream (measured: 70.7 -> 66 ticks per MFMA when idle).
+        const int pw = wave - 4;
         const int bx = a.x_bmod ? (b % a.x_bmod) : b;
         const float* Xg = a.X + (long)bx * a.x_bs;
-        const int tx = t0 - halo + ptid;                // frame this thread stages
-        const bool xin = (ptid < FW) && (tx >= 0) && (tx < a.T);
-        const int txc = min(max(tx, 0), a.T - 1);       // clamped: loads are unconditional (branch-free)
-        const float* Xt = Xg + (long)txc * a.x_fs;
         const int last_plane = a.x_planes - 1;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            float4 xv[XP], xd[XP];
-#pragma unroll
-            for (int pl = 0; pl < XP; ++pl) {
+        const unsigned recs = ((unsigned)(a.T - 1) * (unsigned)a.x_fs + 4u) * 4u;   // bytes of one plane row
+        const int wl = (FW + 63) >> 6;                  // wave-loads per plane row
+        const int total = XP * wl;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        auto issue = [&](int chunk) {
+            for (int i = pw; i < total; i += 4) {
+                const int pl = i / wl, seg = i - pl * wl;
+                const int f = seg * 64 + lane;
+                // planes beyond Cin (K padding) re-read the last valid plane: finite data x zero weights
                 const int pc = min(chunk * XP + pl, last_plane);
-                xv[pl] = *reinterpret_cast<const float4*>(Xt + (long)pc * a.x_ps);
-                xd[pl] = *reinterpret_cast<const float4*>(a.dvec + pc * 4);
+                const __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(Xg + (long)pc * a.x_ps), 0, recs, 0x00020000);
+                const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
+                float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
+                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
             }
-            if (ptid < FW) {
-#pragma unroll
-                for (int pl = 0; pl < XP; ++pl) {
-                    // zero padding applies to (h + d): model/diffwave.py:139-144
-                    const bool ok = xin && (chunk * XP + pl <= last_plane);
-                    float4 v = xv[pl];
-                    v.x = ok ? v.x + xd[pl].x : 0.f;
-                    v.y = ok ? v.y + xd[pl].y : 0.f;
-                    v.z = ok ? v.z + xd[pl].z : 0.f;
-                    v.w = ok ? v.w + xd[pl].w : 0.f;
-                    Xs[((chunk & 1) * XP + pl) * FW + ptid] = v;
-                }
-            }
-            __syncthreads();   // hand-over #chunk (the consumers' matching barrier opens their chunk)
+        };
+#if DR_ABLATE != 9
+        issue(0);
+#endif
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            // hand-over #chunk: __syncthreads() waits for this wave's DMA (vmcnt) before the barrier; the
+            // consumers' matching barrier opens their chunk.  Only then may the OTHER buffer be refilled
+            // (the consumers finished reading it before they arrived here).
+            __syncthreads();
+#if DR_ABLATE != 9
+            if (chunk + 1 < nchunks) issue(chunk + 1);
+#endif
         }
         return;
     }
@@ -152,6 +172,31 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // EPI_RES_SKIP read-modify-writes h (residual rows) or skip (skip rows): those operands come from
+    // HBM, so they are loaded NOW (branch-free) and their latency hides behind the K loop.  Everything
+    // else the epilogues need (bias, d2, conditioner) is L2-resident and is loaded as unconditional
+    // batches at the start of the epilogue: a conditional load there compiles to a branch +
+    // s_waitcnt vmcnt(0) per quad (a chain of serialized round trips), while prefetching all of it here
+    // pushed the kernel over the 256-VGPR budget of a 512-thread block and into scratch.
+    constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_POWER);
+    float4 eop[2][NI][4];
+    if constexpr (EPI == EPI_RES_SKIP) {
+        const bool is_res = (mt * 128 + wr * 64) < a.y_rows;     // wave-uniform row class
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = min(t0 + wc * WN + ni * 32 + r, a.T - 1);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p0 = mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi;
+                    const float* src = is_res ? a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs
+                                              : a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+                    eop[mi][ni][q] = *reinterpret_cast<const float4*>(src);
+                }
+        }
+    }
 
     auto load_a = [&](int slab) -> A8 {
         A8 o;
@@ -219,6 +264,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
         };
         __syncthreads();   // X tile #chunk staged by the producers (matches their hand-over barrier)
+        if (a.dbg && blockIdx.x == 0 && tid == 0 && chunk < 14) a.dbg[2 + chunk] = clock64() - tick0;
         int q = 0;
         for (; q + 2 <= per_chunk; q += 2) {
             at(F_{}, q);
@@ -237,39 +283,67 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // epilogue.  C/D fragment of 32x32: column = lane&31 (frame), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
     // ----------------------------------------------------------------------------------------
+    auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
+    float4 ebias[2][4];                         // [mi][q]
+    float4 ed2[2][4];                           // second-output offset (step embedding of the next conv)
+    {
+        const float* bsrc = a.bias;
+        if constexpr (EPI == EPI_GATE) bsrc = (b < a.n_cond) ? a.bias : a.bias2;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ebias[mi][q] = *reinterpret_cast<const float4*>(bsrc + mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi);
+        if constexpr (EPI == EPI_RELU || EPI == EPI_RES_SKIP) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // residual rows only exist below y_rows; the clamp keeps the (unused) skip-row loads in range
+                    const int p0 = min(mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
+                    ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + p0);
+                }
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int t = t0 + wc * WN + ni * 32 + r;
+        if constexpr (EPI == EPI_GATE) {
+            // conditioner quads of this frame column: one unconditional batch (unconditional samples read
+            // sample 0's tensor - valid memory - and ignore it)
+            const int tc = min(t, a.T - 1);
+            const float* cb = a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs + (long)tc * 4;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p0 = mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi;
+                    eop[mi][ni][q] = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
+                }
+        }
         if (t >= a.T) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int rq = 8 * q + 4 * hi;   // row offset inside a 32-row MFMA tile
-            if constexpr (EPI == EPI_GATE || EPI == EPI_POWER) {
-                const int p0 = mt * 128 + wr * 64 + rq;   // packed row of the gate / cos quad
-                const int p1 = p0 + 32;                   // packed row of the filter / sin quad
+            if constexpr (PAIRED) {
                 const int c0 = mt * 64 + wr * 32 + rq;    // output channel of the quad
                 if (c0 >= a.y_rows) continue;
                 float v0[4], v1[4], o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[1][ni][4 * q + e]; }
                 if constexpr (EPI == EPI_GATE) {
-                    float4 a0, a1;
-                    if (b < a.n_cond) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + p0);
-                        const float4 b1 = *reinterpret_cast<const float4*>(a.bias + p1);
-                        const float* cb = a.cond + (long)b * a.c_bs + (long)t * 4;
-                        const float4 c0v = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
-                        const float4 c1v = *reinterpret_cast<const float4*>(cb + (long)(p1 >> 2) * a.T * 4);
-                        a0 = make_float4(b0.x + c0v.x, b0.y + c0v.y, b0.z + c0v.z, b0.w + c0v.w);
-                        a1 = make_float4(b1.x + c1v.x, b1.y + c1v.y, b1.z + c1v.z, b1.w + c1v.w);
-                    } else {
-                        a0 = *reinterpret_cast<const float4*>(a.bias2 + p0);
-                        a1 = *reinterpret_cast<const float4*>(a.bias2 + p1);
-                    }
-                    const float ad0[4] = {a0.x, a0.y, a0.z, a0.w};
-                    const float ad1[4] = {a1.x, a1.y, a1.z, a1.w};
+                    // y = conv + b_conv + (Wc spec + bc)   [model/diffwave.py:143-144]; unconditional samples
+                    // carry the constant conditioner inside bias2
+                    float b0[4], b1[4], c0v[4], c1v[4];
+                    f4arr(ebias[0][q], b0); f4arr(ebias[1][q], b1);
+                    f4arr(eop[0][ni][q], c0v); f4arr(eop[1][ni][q], c1v);
+                    const bool has_c = b < a.n_cond;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v0[e] + ad0[e]) * tanhf(v1[e] + ad1[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
+                        const float a1 = has_c ? b1[e] + c1v[e] : b1[e];
+                        o[e] = sigmoidf_(v0[e] + a0) * tanhf(v1[e] + a1);   // gate = first half, filter = second (:146-147)
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
@@ -280,40 +354,35 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const int p0 = mt * 128 + wr * 64 + mi * 32 + rq;
-                    float v[4];
+                    float v[4], bb[4], o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
-                    float bb[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) {
-                        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + p0);
-                        bb[0] = b4.x; bb[1] = b4.y; bb[2] = b4.z; bb[3] = b4.w;
-                    }
+                    f4arr(ebias[mi][q], bb);
                     if constexpr (EPI == EPI_RES_SKIP) {
+                        float pv[4];
+                        f4arr(eop[mi][ni][q], pv);
                         // packed rows [0, y_rows) are the residual half, [y_rows, 2*y_rows) the skip half
                         // (y_rows is a multiple of 64, so the branch is wave-uniform)
-                        if (p0 < a.y_rows) {   // h = (h + (acc + b)) / sqrt(2), in place
+                        if (p0 < a.y_rows) {   // h = (h + (acc + b)) / sqrt(2), in place (:151)
                             float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                            const float4 h4 = *reinterpret_cast<const float4*>(dst);
-                            const float hh[4] = {h4.x, h4.y, h4.z, h4.w};
-                            float o[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (hh[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                            for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
                             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                        } else {           // skip rows
-                            const int ps = (p0 - a.y_rows) >> 2;
-                            float* dst = a.skip + (long)b * a.s_bs + ((long)ps * a.T + t) * 4;
-                            float o[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = v[e] + bb[e];
-                            if (!a.skip_init) {
-                                const float4 s4 = *reinterpret_cast<const float4*>(dst);
-                                o[0] += s4.x; o[1] += s4.y; o[2] += s4.z; o[3] += s4.w;
+                            if (a.Y2) {        // hd = h + d_{l+1}: the next dilated conv's input (:139)
+                                float dd[4];
+                                f4arr(ed2[mi][q], dd);
+                                float* dst2 = a.Y2 + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                *reinterpret_cast<float4*>(dst2) =
+                                    make_float4(o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]);
                             }
+                        } else {               // skip (+)= acc + b (:680)
+                            float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
                             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                         }
                     } else {
                         if (p0 >= a.y_rows) continue;
-                        float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if constexpr (EPI == EPI_PLAIN) o[e] = a.alpha * v[e] + bb[e];
@@ -323,6 +392,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                         }
                         float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        if constexpr (EPI == EPI_RELU) {
+                            if (a.Y2) {    // hd = h + d_0 for the first dilated conv
+                                float dd[4];
+                                f4arr(ed2[mi][q], dd);
+                                float* dst2 = a.Y2 + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                *reinterpret_cast<float4*>(dst2) =
+                                    make_float4(o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]);
+                            }
+                        }
                     }
                 }
             }
@@ -346,8 +424,13 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 64 * NI;
     const int tps = (a.T + BN - 1) / BN;
     const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil);
-    const dim3 grid((unsigned)(a.MT * a.NB * tps));
-    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI>), grid, dim3(512), lds, s, a);
+    const int NT = a.NB * tps;
+    const dim3 grid((unsigned)(a.MT * NT));
+    GemmArgs b = a;
+    // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
+    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
 }
 
@@ -374,7 +457,9 @@ hipError_t init_kernels() {
     if ((e = init_gemm_ni<1, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_ni<2, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_ni<1, 2>()) != hipSuccess) return e;
-    return init_gemm_ni<2, 2>();
+    if ((e = init_gemm_ni<2, 2>()) != hipSuccess) return e;
+    if ((e = init_gemm_ni<1, 4>()) != hipSuccess) return e;
+    return init_gemm_ni<2, 4>();
 }
 
 template <int NI, int KS>
@@ -394,10 +479,16 @@ static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s) {
     const int halo = ((a.taps - 1) / 2) * a.dil;
     if (64 * NI + 2 * halo > 256 || a.kchunks < 1) return hipErrorInvalidValue;
-    // 1x1 GEMMs restage X every step: take 64 channels per chunk there (half the barriers)
-    const int KS = (a.taps == 1 && a.kchunks % 2 == 0) ? 2 : 1;
-    if (NI == 1) return KS == 2 ? launch_gemm_ni<1, 2>(a, epi, s) : launch_gemm_ni<1, 1>(a, epi, s);
-    if (NI == 2) return KS == 2 ? launch_gemm_ni<2, 2>(a, epi, s) : launch_gemm_ni<2, 1>(a, epi, s);
+    // 1x1 GEMMs restage X every step: take up to 128 channels per chunk there (fewer hand-overs)
+    const int KS = a.taps != 1 ? 1 : (a.kchunks % 4 == 0 ? 4 : (a.kchunks % 2 == 0 ? 2 : 1));
+    if (NI == 1) {
+        if (KS == 4) return launch_gemm_ni<1, 4>(a, epi, s);
+        return KS == 2 ? launch_gemm_ni<1, 2>(a, epi, s) : launch_gemm_ni<1, 1>(a, epi, s);
+    }
+    if (NI == 2) {
+        if (KS == 4) return launch_gemm_ni<2, 4>(a, epi, s);
+        return KS == 2 ? launch_gemm_ni<2, 2>(a, epi, s) : launch_gemm_ni<2, 1>(a, epi, s);
+    }
     return hipErrorInvalidValue;
 }
 

@@ -174,6 +174,10 @@ class Engine:
         self._check(self.lib.dr_profile_read(self.h, C.byref(n), C.byref(ms), 1 if reset else 0))
         return n.value, ms.value
 
+    def bench_pointwise(self, layer: int, NB: int, T: int):
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_bench_pointwise(self.h, layer, NB, T, self._stream()))
+
     def debug_ticks(self) -> Tuple[int, int]:
         a = C.c_int64(0)
         b = C.c_int64(0)

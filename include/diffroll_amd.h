@@ -158,6 +158,9 @@ int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset
 /* Standalone launch of the fused dilated-conv+gate kernel of layer `layer` on the engine's
  * workspace activations (for micro-benchmarks / roofline): returns 0. */
 int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, void* stream);
+/* Same for the 1x1 output projection + residual/skip kernel of layer `layer` (in place on the
+ * workspace: repeated launches keep rescaling h, which is harmless for timing). */
+int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream);
 /* s_memtime ticks (shader clock) block 0 of the last dr_bench_layer launch spent in its K loop / in
  * total: with the wall time this gives the effective clock the kernel ran at. */
 int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks);

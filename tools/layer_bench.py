@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--layers", default="0,1,2,3")
     ap.add_argument("--uncond", action="store_true", help="all samples unconditional (generation)")
+    ap.add_argument("--pointwise", action="store_true", help="time the 1x1 output projection kernel instead")
     args = ap.parse_args()
     hp = dict(bench.HP)
     hp["kernel_size"] = args.k
@@ -38,6 +39,25 @@ def main():
     if n_cond:
         eng.forward(x, 100, uncond=False)
     flops = 2.0 * 512 * 1024 * args.k * NB * args.T
+    if args.pointwise:
+        flops = 2.0 * 512 * 1024 * NB * args.T
+        for layer in [int(v) for v in args.layers.split(",")]:
+            for _ in range(5):
+                eng.bench_pointwise(layer, NB, args.T)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                eng.bench_pointwise(layer, NB, args.T)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            lt, bt = eng.debug_ticks()
+            nmfma = 64 * (hp["residual_channels"] // 32)
+            print(f"1x1 layer {layer:2d} NB={NB} T={args.T}: {us:8.2f} us  {flops / us / 1e6:7.2f} TFLOP/s | block0 ticks: "
+                  f"loop {lt} total {bt} ({bt / 2.33e3:.1f} us at 2.33 GHz), loop ticks/MFMA {lt / nmfma:.1f}", flush=True)
+        return
     for layer in [int(v) for v in args.layers.split(",")]:
         for _ in range(5):
             eng.bench_layer(layer, NB, args.T, 100, n_cond)
