@@ -191,11 +191,18 @@ size_t expected_numel(const dr_engine* e, const std::string& name) {
     return 0;
 }
 
-int pick_ni(int taps, int dil) {
+// Frame-tile size (NI = 1: 64 frames, 2: 128 frames per block) for a GEMM of MT row tiles over NB samples
+// of T frames: minimise (block rounds over the 256 CUs) x (tile cost); 128-frame tiles win ties (half the
+// weight traffic per MFMA).  One block per CU is resident (LDS / 512-thread blocks).
+int pick_ni(int MT, int NB, int T, int taps, int dil) {
     const int halo = ((taps - 1) / 2) * dil;
     static const int forced = getenv("DR_CONV_NI") ? atoi(getenv("DR_CONV_NI")) : 0;   // tuning experiments
-    if (forced == 1 || (forced == 2 && 128 + 2 * halo <= 256)) return forced;
-    return (128 + 2 * halo <= 256) ? 2 : 1;
+    const bool fits2 = 128 + 2 * halo <= 256;
+    if (forced == 1 || (forced == 2 && fits2)) return forced;
+    if (!fits2) return 1;
+    const long b2 = (long)MT * NB * ((T + 127) / 128), b1 = (long)MT * NB * ((T + 63) / 64);
+    const long c2 = ((b2 + 255) / 256) * 2, c1 = (b1 + 255) / 256;
+    return c1 < c2 ? 1 : 2;
 }
 
 // common GemmArgs for a P4 activation input [NB][planes][T][4]
@@ -247,7 +254,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
         p4_out(a, e->h, P, T, Cp);
         a.Y2 = e->hd; a.d2 = e->d_dtab + (size_t)t * L * Cp;     // hd = h + d_0 (model/diffwave.py:138-139)
-        HIPCHK(e, launch_gemm(a, EPI_RELU, 2, st));
+        HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
@@ -261,7 +268,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             p4_out(a, e->g, P, T, Cp);
             const bool timed = e->prof && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(e->K, w.dil), st));
+            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), st));
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
         }
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
@@ -269,8 +276,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             p4_out(a, e->h, P, T, Cp);
             if (l + 1 < L) { a.Y2 = e->hd; a.d2 = e->d_dtab + ((size_t)t * L + l + 1) * Cp; }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
-            static const int ni_1x1 = getenv("DR_1X1_NI") ? atoi(getenv("DR_1X1_NI")) : 2;   // tuning experiments
-            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, ni_1x1, st));
+            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, pick_ni(Cp / 64, NB, T, 1, 1), st));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
@@ -793,7 +799,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(e->K, w.dil), (hipStream_t)stream));
+    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), (hipStream_t)stream));
     return DR_OK;
 }
 
@@ -815,8 +821,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    static const int ni_1x1 = getenv("DR_1X1_NI") ? atoi(getenv("DR_1X1_NI")) : 2;
-    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, ni_1x1, (hipStream_t)stream));
+    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, pick_ni(Cp / 64, NB, T, 1, 1), (hipStream_t)stream));
     return DR_OK;
 }
 
