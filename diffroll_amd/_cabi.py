@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 1
+DR_ABI_VERSION = 2
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
 
 SAMPLERS = {
@@ -19,6 +19,11 @@ SAMPLERS = {
     "cfdg_ddpm_x0": 1,
     "generation_ddpm_x0": 2,
     "inpainting_ddpm_x0": 3,
+    "ddim_x0": 4,
+    "cfdg_ddim_x0": 5,
+    "ddpm": 6,          # epsilon prediction (task/diffusion.py:804-829)
+    "ddim": 7,          # epsilon prediction (:877-892)
+    "ddim2ddpm": 8,     # epsilon prediction (:894-911)
 }
 COND_SPEC, COND_UNCOND = 0, 1
 

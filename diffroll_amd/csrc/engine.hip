@@ -24,6 +24,7 @@ struct LayerW {
     float* conv_w = nullptr;     // packed (paired rows) [MTc][kch][k] slabs
     float* conv_b = nullptr;     // packed-row bias (conditional samples; cond tensor carries bc)
     float* conv_b_u = nullptr;   // packed-row bias for unconditional samples: b_conv + (bc - sum_m Wc)
+    float* conv_b_z = nullptr;   // ... for spec == 0 samples (cfdg_ddim_x0's second branch): b_conv + bc
     float* out_w = nullptr;      // packed (natural halves) 1x1
     float* out_b = nullptr;
     float* cond_w = nullptr;     // packed (paired rows) conditioner 1x1
@@ -55,7 +56,7 @@ struct dr_engine {
     bool committed = false;
 
     // device constants
-    float* d_coef = nullptr;   // (S,5)
+    float* d_coef = nullptr;   // (DR_COEF_FAMILIES, S, 5)
     float* d_dtab = nullptr;   // (S, L, Cp)   hoisted diffusion_projection(diffusion_embedding(t))
     std::vector<LayerW> layers;
     float *in_w = nullptr, *in_b = nullptr, *skip_w = nullptr, *skip_b = nullptr, *outp_w = nullptr, *outp_b = nullptr;
@@ -244,7 +245,7 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
 // One network evaluation for NB samples (first n_cond conditional) at step t.
 //   xin (B,T,88) rows are used modulo bmod (classifier-free batching: 2B evaluations of B inputs).
 int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, int T, int t, float* x0_out,
-                hipStream_t st) {
+                hipStream_t st, bool zero_spec = false) {
     const int Cp = e->Cp, P = Cp / 4, L = e->L;
     // input projection + relu (model/diffwave.py:667-668)
     {
@@ -260,7 +261,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         const LayerW& w = e->layers[l];
         {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
             GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
-            a.bias2 = w.conv_b_u;
+            a.bias2 = zero_spec ? w.conv_b_z : w.conv_b_u;   // samples >= n_cond: spec == 0 or spec == -1
             a.taps = e->K; a.dil = w.dil;
             a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
             a.c_bs = (long)2 * Cp * T;
@@ -293,25 +294,36 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     return DR_OK;
 }
 
-int sampler_shape(int sampler, int B, int& NB, int& n_cond) {
+int sampler_shape(int sampler, int B, int& NB, int& n_cond, int& family, bool& zero_spec) {
+    zero_spec = false;
     switch (sampler) {
-        case DR_SAMPLER_DDPM_X0: NB = B; n_cond = B; return DR_OK;
+        case DR_SAMPLER_DDPM_X0: NB = B; n_cond = B; family = DR_COEF_DDPM_X0; return DR_OK;
         case DR_SAMPLER_CFDG_DDPM_X0:
-        case DR_SAMPLER_INPAINTING_DDPM_X0: NB = 2 * B; n_cond = B; return DR_OK;
-        case DR_SAMPLER_GENERATION_DDPM_X0: NB = B; n_cond = 0; return DR_OK;
+        case DR_SAMPLER_INPAINTING_DDPM_X0: NB = 2 * B; n_cond = B; family = DR_COEF_DDPM_X0; return DR_OK;
+        case DR_SAMPLER_GENERATION_DDPM_X0: NB = B; n_cond = 0; family = DR_COEF_DDPM_X0; return DR_OK;
+        case DR_SAMPLER_DDIM_X0: NB = B; n_cond = B; family = DR_COEF_DDIM_X0; return DR_OK;
+        case DR_SAMPLER_CFDG_DDIM_X0: NB = 2 * B; n_cond = B; family = DR_COEF_DDIM_X0; zero_spec = true; return DR_OK;
+        case DR_SAMPLER_DDPM_EPS: NB = B; n_cond = B; family = DR_COEF_DDPM_EPS; return DR_OK;
+        case DR_SAMPLER_DDIM_EPS: NB = B; n_cond = B; family = DR_COEF_DDIM_EPS; return DR_OK;
+        case DR_SAMPLER_DDIM2DDPM_EPS: NB = B; n_cond = B; family = DR_COEF_DDIM2DDPM_EPS; return DR_OK;
     }
     return DR_EINVAL;
+}
+int sampler_shape(int sampler, int B, int& NB, int& n_cond) {
+    int fam; bool z;
+    return sampler_shape(sampler, B, NB, n_cond, fam, z);
 }
 
 int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int T, int t, float w, uint64_t seed,
              int first_sample, hipStream_t st) {
-    int NB, n_cond;
-    if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
-    int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st);
+    int NB, n_cond, family;
+    bool zero_spec;
+    if (sampler_shape(sampler, B, NB, n_cond, family, zero_spec)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
+    int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st, zero_spec);
     if (rc) return rc;
     UpdateArgs u{};
     u.x = x; u.x0c = e->x0buf; u.x0u = (NB == 2 * B) ? e->x0buf + (size_t)B * T * 88 : nullptr;
-    u.noise = noise; u.coef = e->d_coef + (size_t)t * 5; u.t = t;
+    u.noise = noise; u.coef = e->d_coef + ((size_t)family * e->S + t) * 5; u.t = t; u.mode = family;
     u.n = (long)B * T * 88; u.per_sample = (long)T * 88;
     u.w = w; u.onepw = (float)(1.0 + (double)w);
     u.seed = seed; u.first_sample = first_sample;
@@ -420,7 +432,7 @@ int dr_set_param(dr_engine* e, const char* name, const float* host_data, size_t 
 int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_coef) {
     if (!e || !host_embedding || !host_coef) return fail(e, DR_EINVAL, "null argument");
     e->h_emb.assign(host_embedding, host_embedding + (size_t)e->S * 128);
-    e->h_coef.assign(host_coef, host_coef + (size_t)e->S * 5);
+    e->h_coef.assign(host_coef, host_coef + (size_t)DR_COEF_FAMILIES * e->S * 5);
     e->committed = false;
     return DR_OK;
 }
@@ -482,7 +494,7 @@ int dr_commit(dr_engine* e, void* stream) {
             int mi, c; paired_row(pr, mi, c);
             return (c < C && ch < NM) ? Wc[(size_t)(mi * C + c) * NM + ch] : 0.f;
         });
-        std::vector<float> bconv(MTc * 128, 0.f), bconv_u(MTc * 128, 0.f), bcond(MTc * 128, 0.f);
+        std::vector<float> bconv(MTc * 128, 0.f), bconv_u(MTc * 128, 0.f), bconv_z(MTc * 128, 0.f), bcond(MTc * 128, 0.f);
         for (int pr = 0; pr < MTc * 128; ++pr) {
             int mi, c; paired_row(pr, mi, c);
             if (c >= C) continue;
@@ -492,6 +504,7 @@ int dr_commit(dr_engine* e, void* stream) {
             const float cu = (float)((double)Bc[o] - sw);   // conditioner of spec == -1 (model/diffwave.py:660)
             bconv[pr] = Bd[o];
             bconv_u[pr] = Bd[o] + cu;
+            bconv_z[pr] = Bd[o] + Bc[o];                    // conditioner of spec == 0 is its bias
             bcond[pr] = Bc[o];
         }
         // 1x1 output projection (2C,C,1): packed rows [0,Cp) residual, [Cp,2Cp) skip
@@ -505,7 +518,8 @@ int dr_commit(dr_engine* e, void* stream) {
             if (c < C) bout[pr] = Bo[half * C + c];
         }
         if ((rc = upload(e, pconv, &lw.conv_w)) || (rc = upload(e, bconv, &lw.conv_b)) ||
-            (rc = upload(e, bconv_u, &lw.conv_b_u)) || (rc = upload(e, pcond, &lw.cond_w)) ||
+            (rc = upload(e, bconv_u, &lw.conv_b_u)) || (rc = upload(e, bconv_z, &lw.conv_b_z)) ||
+            (rc = upload(e, pcond, &lw.cond_w)) ||
             (rc = upload(e, bcond, &lw.cond_b)) || (rc = upload(e, pout, &lw.out_w)) ||
             (rc = upload(e, bout, &lw.out_b)))
             return rc;
@@ -565,8 +579,8 @@ int dr_commit(dr_engine* e, void* stream) {
         if ((rc = upload(e, pm, &e->mel_w))) return rc;
     }
     // ---- tables ------------------------------------------------------------------------------
-    if ((rc = dev_alloc(e, &e->d_coef, (size_t)S * 5))) return rc;
-    HIPCHK(e, hipMemcpy(e->d_coef, e->h_coef.data(), (size_t)S * 5 * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(e, &e->d_coef, (size_t)DR_COEF_FAMILIES * S * 5))) return rc;
+    HIPCHK(e, hipMemcpy(e->d_coef, e->h_coef.data(), (size_t)DR_COEF_FAMILIES * S * 5 * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = dev_alloc(e, &e->d_dtab, (size_t)S * L * Cp))) return rc;
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by

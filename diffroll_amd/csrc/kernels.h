@@ -81,6 +81,7 @@ struct UpdateArgs {
     const float* noise;    // (B, T, 88) or null -> philox
     const float* coef;     // device pointer to this step's 5 coefficients
     int t;                 // step index
+    int mode;              // coefficient family (DR_COEF_*): 0/1 x0 update, 2 eps ddpm, 3 eps ddim, 4 eps ddim2ddpm
     long n;                // B*T*88
     long per_sample;       // T*88
     float w, onepw;

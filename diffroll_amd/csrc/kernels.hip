@@ -537,15 +537,16 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) x0[e] = a.onepw * x0[e] - a.w * u[e];
     }
-    const float c_prev = a.coef[0], c_dir = a.coef[1], sac_t = a.coef[2], s1m_t = a.coef[3], sigma = a.coef[4];
+    const float c0 = a.coef[0], c1 = a.coef[1], c2 = a.coef[2], c3 = a.coef[3], c4 = a.coef[4];
     float o[4];
-    if (a.t == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = x0[e] / sac_t;
-    } else {
+    // which updates draw noise at t > 0: x0 DDPM (0), eps ddpm (2), eps ddim2ddpm (4)
+    const bool noisy = (a.mode == 0 || a.mode == 2 || a.mode == 4) && a.t > 0;
+    float x[4] = {0.f, 0.f, 0.f, 0.f}, z[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.t > 0 || a.mode >= 2) {
         const float4 xv = reinterpret_cast<const float4*>(a.x)[i4];
-        const float x[4] = {xv.x, xv.y, xv.z, xv.w};
-        float z[4];
+        x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
+    }
+    if (noisy) {
         if (a.noise) {
             const float4 zv = reinterpret_cast<const float4*>(a.noise)[i4];
             z[0] = zv.x; z[1] = zv.y; z[2] = zv.z; z[3] = zv.w;
@@ -559,12 +560,28 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
             box_muller(rnd[0], rnd[1], z[0], z[1]);
             box_muller(rnd[2], rnd[3], z[2], z[3]);
         }
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float t1 = c_prev * x0[e];
-            const float t2 = (c_dir * (x[e] - sac_t * x0[e])) / s1m_t;
-            const float t3 = sigma * z[e];
-            o[e] = (t1 + t2) + t3;
+    for (int e = 0; e < 4; ++e) {
+        const float y = x0[e];   // network output: x0 prediction (modes 0/1) or epsilon (modes 2-4)
+        if (a.mode <= 1) {
+            // ddpm_x0 family :957-967 / ddim_x0 family :864-873 (c4 = sigma = 0, the 0*z term is dropped)
+            if (a.t == 0) o[e] = y / c2;
+            else {
+                const float t1 = c0 * y;
+                const float t2 = (c1 * (x[e] - c2 * y)) / c3;
+                o[e] = (a.mode == 0) ? (t1 + t2) + c4 * z[e] : (t1 + t2);
+            }
+        } else if (a.mode == 2) {
+            // ddpm :820-829: sqrt_recip_alphas_t * (x - betas_t * eps / sqrt_1m_acp_t) [+ sqrt(post_var_t) * z]
+            const float m = c0 * (x[e] - (c1 * y) / c2);
+            o[e] = (a.t == 0) ? m : m + c3 * z[e];
+        } else {
+            // ddim :885-890 / ddim2ddpm :902-909
+            const float xe = (x[e] - c3 * y) / c2;
+            if (a.t == 0) o[e] = xe;
+            else if (a.mode == 3) o[e] = c0 * xe + c1 * y;
+            else o[e] = (c0 * xe + c1 * y) + c4 * z[e];
         }
     }
     reinterpret_cast<float4*>(a.x)[i4] = make_float4(o[0], o[1], o[2], o[3]);

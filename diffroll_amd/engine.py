@@ -11,7 +11,7 @@ from typing import Dict, Optional, Sequence, Tuple
 import torch
 
 from . import _cabi
-from .schedule import build_embedding, make_schedule, posterior_coef_table
+from .schedule import build_embedding, make_schedule, sampler_coef_tables
 
 
 class EngineError(RuntimeError):
@@ -63,7 +63,7 @@ class Engine:
         self.h = h
         self.schedule = make_schedule(beta_start, beta_end, timesteps)
         self._tables = (build_embedding(timesteps).contiguous().float(),
-                        posterior_coef_table(self.schedule).contiguous())
+                        sampler_coef_tables(self.schedule).contiguous())
         self._check(self.lib.dr_set_tables(
             self.h, C.cast(self._tables[0].data_ptr(), C.POINTER(C.c_float)),
             C.cast(self._tables[1].data_ptr(), C.POINTER(C.c_float))))

@@ -24,7 +24,9 @@ import torch.nn as nn
 
 from .engine import Engine
 
-_SAMPLERS = ("ddpm_x0", "cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0")
+_SAMPLERS = ("ddpm_x0", "cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0",
+             "ddim_x0", "cfdg_ddim_x0", "ddpm", "ddim", "ddim2ddpm")
+_GUIDED = ("cfdg_ddpm_x0", "inpainting_ddpm_x0", "cfdg_ddim_x0")
 
 
 class AttrDict(dict):
@@ -113,8 +115,6 @@ class ClassifierFreeDiffRoll(nn.Module):
         training = _attr(training if training is not None else {"mode": "x_0"})
         spec_args = _attr(dict(spec_args))
         if sampling.type not in _SAMPLERS:
-            if hasattr(self, sampling.type) or sampling.type in ("ddpm", "ddim", "ddim_x0", "ddim2ddpm", "cfdg_ddim_x0"):
-                raise NotImplementedError(f"sampler '{sampling.type}' is not part of the hot path (SURVEY.md 8f-3)")
             raise AttributeError(sampling.type)                               # getattr at task/diffusion.py:255
         self.hparams = AttrDict(
             residual_channels=residual_channels, unconditional=unconditional, condition=condition,
@@ -256,7 +256,7 @@ class ClassifierFreeDiffRoll(nn.Module):
         else:
             Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
         xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
-        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0") else 0.0
+        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         z = None
         if noise is not None:
             z = noise.to(eng.device, torch.float32).reshape(B, Tm, 88).contiguous()
@@ -282,6 +282,27 @@ class ClassifierFreeDiffRoll(nn.Module):
     def inpainting_ddpm_x0(self, x, waveform, t_index, noise=None):
         """task/diffusion.py:999-1025."""
         return self._one_step("inpainting_ddpm_x0", x, waveform, t_index, noise)
+
+    # SURVEY.md 8f-3: same kernels, other per-step coefficients
+    def ddim_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:855-875 (sigma = 0; `noise` is accepted and ignored, as 0 * randn_like)."""
+        return self._one_step("ddim_x0", x, waveform, t_index, noise)
+
+    def cfdg_ddim_x0(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:1027-1055 (second branch: spectrogram of a zero waveform = all 0, not -1)."""
+        return self._one_step("cfdg_ddim_x0", x, waveform, t_index, noise)
+
+    def ddpm(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:804-829 (network output interpreted as epsilon)."""
+        return self._one_step("ddpm", x, waveform, t_index, noise)
+
+    def ddim(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:877-892 (epsilon prediction, deterministic)."""
+        return self._one_step("ddim", x, waveform, t_index, noise)
+
+    def ddim2ddpm(self, x, waveform, t_index, noise=None):
+        """task/diffusion.py:894-911 (epsilon prediction)."""
+        return self._one_step("ddim2ddpm", x, waveform, t_index, noise)
 
     # ------------------------------------------------------------------ whole chain
     @torch.no_grad()
@@ -316,7 +337,7 @@ class ClassifierFreeDiffRoll(nn.Module):
             z = noise.to(eng.device, torch.float32).reshape(S, B, T, 88)
             if Tm != T or not z.is_contiguous():
                 z = z[:, :, :Tm, :].contiguous()
-        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0") else 0.0
+        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         eng.sample(sampler, xb, z, w, seed, first_sample, use_graph)
         return xb.clone().unsqueeze(1), spec
 

@@ -67,3 +67,41 @@ def build_embedding(max_steps: int) -> torch.Tensor:
     dims = torch.arange(64).unsqueeze(0)
     table = steps * 10.0 ** (dims * 4.0 / 63.0)
     return torch.cat([torch.sin(table), torch.cos(table)], dim=1)
+
+
+def sampler_coef_tables(sch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """(5, S, 5) fp32: one table of per-step scalars per coefficient family (DR_COEF_* in
+    include/diffroll_amd.h), each scalar evaluated with the reference's own torch expression:
+      0 ddpm_x0 family   task/diffusion.py:957-967   (posterior_coef_table)
+      1 ddim_x0 family   :864-873, :1044-1053        (sigma = 0)
+      2 ddpm  (epsilon)  :807-829    [sqrt_recip_alphas[t], betas[t], sqrt_1m_acp[t], sqrt(posterior_variance[t]), 0]
+      3 ddim  (epsilon)  :885-890    [sqrt_acp[t-1], sqrt_1m_acp[t-1], sqrt_acp[t], sqrt_1m_acp[t], 0]
+      4 ddim2ddpm (eps)  :902-909    [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]**2 - sigma**2), sqrt_acp[t], sqrt_1m_acp[t], sigma]
+    """
+    sac = sch["sqrt_alphas_cumprod"]
+    s1m = sch["sqrt_one_minus_alphas_cumprod"]
+    alphas = sch["alphas"]
+    S = sac.shape[0]
+    out = torch.zeros(5, S, 5, dtype=torch.float32)
+    out[0] = posterior_coef_table(sch)
+    for t in range(S):
+        out[1, t, 2] = sac[t]
+        out[1, t, 3] = s1m[t]
+        out[2, t, 0] = sch["sqrt_recip_alphas"][t]
+        out[2, t, 1] = sch["betas"][t]
+        out[2, t, 2] = s1m[t]
+        out[2, t, 3] = torch.sqrt(sch["posterior_variance"][t])
+        for fam in (3, 4):
+            out[fam, t, 2] = sac[t]
+            out[fam, t, 3] = s1m[t]
+        if t > 0:
+            sigma = 0
+            out[1, t, 0] = sac[t - 1]
+            out[1, t, 1] = torch.sqrt(1 - sac[t - 1] ** 2 - sigma ** 2)
+            out[3, t, 0] = sac[t - 1]
+            out[3, t, 1] = s1m[t - 1]
+            sigma = (s1m[t - 1] / s1m[t]) * torch.sqrt(1 - alphas[t])
+            out[4, t, 0] = sac[t - 1]
+            out[4, t, 1] = torch.sqrt(1 - sac[t - 1] ** 2 - sigma ** 2)
+            out[4, t, 4] = sigma
+    return out

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 1
+#define DR_ABI_VERSION 2
 
 enum {
     DR_OK = 0,
@@ -52,8 +52,25 @@ enum {
     DR_SAMPLER_DDPM_X0 = 0,        /* :831-853  one conditional evaluation            */
     DR_SAMPLER_CFDG_DDPM_X0 = 1,   /* :943-969  conditional + unconditional, weight w */
     DR_SAMPLER_GENERATION_DDPM_X0 = 2, /* :971-997  one unconditional evaluation (spec = -1) */
-    DR_SAMPLER_INPAINTING_DDPM_X0 = 3  /* :999-1025 as cfdg; spectrogram frames/bins masked by
+    DR_SAMPLER_INPAINTING_DDPM_X0 = 3, /* :999-1025 as cfdg; spectrogram frames/bins masked by
                                           dr_frontend's mask arguments */
+    /* the remaining samplers = the same kernels with other per-step coefficients */
+    DR_SAMPLER_DDIM_X0 = 4,            /* :855-875   x0 update with sigma = 0                      */
+    DR_SAMPLER_CFDG_DDIM_X0 = 5,       /* :1027-1055 as ddim_x0 with guidance; its second branch is
+                                          forward(zero waveform) WITHOUT sampling=True: spec == 0  */
+    DR_SAMPLER_DDPM_EPS = 6,           /* :804-829   network output is epsilon ("ddpm")            */
+    DR_SAMPLER_DDIM_EPS = 7,           /* :877-892   ("ddim")                                      */
+    DR_SAMPLER_DDIM2DDPM_EPS = 8       /* :894-911   ("ddim2ddpm")                                 */
+};
+
+/* coefficient families of dr_set_tables' `coef` argument */
+enum {
+    DR_COEF_DDPM_X0 = 0,   /* [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]^2 - sigma^2), sqrt_acp[t], sqrt_1m_acp[t], sigma] */
+    DR_COEF_DDIM_X0 = 1,   /* same with sigma = 0                                                          */
+    DR_COEF_DDPM_EPS = 2,  /* [sqrt_recip_alphas[t], betas[t], sqrt_1m_acp[t], sqrt(posterior_variance[t]), 0] */
+    DR_COEF_DDIM_EPS = 3,  /* [sqrt_acp[t-1], sqrt_1m_acp[t-1], sqrt_acp[t], sqrt_1m_acp[t], 0]            */
+    DR_COEF_DDIM2DDPM_EPS = 4, /* [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]^2 - sigma^2), sqrt_acp[t], sqrt_1m_acp[t], sigma] */
+    DR_COEF_FAMILIES = 5
 };
 
 /* which spectrogram a dr_forward evaluation sees (model/diffwave.py:656-660) */
@@ -109,9 +126,10 @@ int dr_set_param(dr_engine* e, const char* name, const float* host_data, size_t 
 /*
  * Host-built tables (same torch expressions as the reference, so bit-equal):
  *   embedding  (timesteps, 128)  DiffusionEmbedding._build_embedding (model/diffwave.py:83-88)
- *   coef       (timesteps, 5)    per-step scalars of task/diffusion.py:957-967:
- *                                [sqrt_acp[t-1], sqrt(1 - sqrt_acp[t-1]^2 - sigma^2), sqrt_acp[t],
- *                                 sqrt_1m_acp[t], sigma];  row 0: [., ., sqrt_acp[0], ., .]
+ *   coef       (DR_COEF_FAMILIES, timesteps, 5)  per-step scalars of the samplers' updates
+ *                                (task/diffusion.py:957-967 and :804-911), one table per coefficient
+ *                                family, columns as listed at the DR_COEF_* enum; row 0 of the x0
+ *                                families only uses column 2 (x = x0 / sqrt_acp[0]).
  */
 int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_coef);
 

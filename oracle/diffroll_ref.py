@@ -14,7 +14,9 @@ arithmetic of the reference path (all file:line are under /root/reference):
   * spectrogram normalisation model/utils.py:21-32
   * samplers                  task/diffusion.py:831-853 (ddpm_x0), :943-969
                               (cfdg_ddpm_x0), :971-997 (generation_ddpm_x0),
-                              :999-1025 (inpainting_ddpm_x0)
+                              :999-1025 (inpainting_ddpm_x0), :855-875 (ddim_x0),
+                              :1027-1055 (cfdg_ddim_x0), :804-829 (ddpm), :877-892
+                              (ddim), :894-911 (ddim2ddpm)
   * the sampling loop         task/diffusion.py:528-534 / :779-788
   * mel front-end             torchaudio==0.11.0 MelSpectrogram (third party,
                               NOT in /root/reference; pinned in
@@ -268,6 +270,40 @@ def posterior_update(sch: Dict[str, Tensor], x: Tensor, x0_pred: Tensor, t_index
             x - sac[t_index] * x0_pred) / s1m[t_index]) + (sigma * z)
 
 
+def eps_update(sch: Dict[str, Tensor], sampler: str, x: Tensor, eps: Tensor, t_index: int,
+               z: Optional[Tensor]) -> Tensor:
+    """The epsilon-prediction updates: ddpm (task/diffusion.py:804-829), ddim (:877-892),
+    ddim2ddpm (:894-911).  Same expressions, same order."""
+    sac = sch["sqrt_alphas_cumprod"]
+    s1m = sch["sqrt_one_minus_alphas_cumprod"]
+    if sampler == "ddpm":
+        model_mean = sch["sqrt_recip_alphas"][t_index] * (x - sch["betas"][t_index] * eps / s1m[t_index])
+        if t_index == 0:
+            return model_mean
+        return model_mean + torch.sqrt(sch["posterior_variance"][t_index]) * z
+    if t_index == 0:
+        return (x - s1m[t_index] * eps) / sac[t_index]
+    if sampler == "ddim":
+        return (sac[t_index - 1]) * ((x - s1m[t_index] * eps) / sac[t_index]) + (s1m[t_index - 1] * eps)
+    if sampler == "ddim2ddpm":
+        sigma = (s1m[t_index - 1] / s1m[t_index]) * torch.sqrt(1 - sch["alphas"][t_index])
+        return (sac[t_index - 1]) * ((x - s1m[t_index] * eps) / sac[t_index]) + (
+            torch.sqrt(1 - sac[t_index - 1] ** 2 - sigma ** 2) * eps) + sigma * z
+    raise ValueError(sampler)
+
+
+def ddim_x0_update(sch: Dict[str, Tensor], x: Tensor, x0_pred: Tensor, t_index: int) -> Tensor:
+    """ddim_x0 / cfdg_ddim_x0 (task/diffusion.py:864-873, :1044-1053): the x0 update with sigma = 0
+    (the reference still adds 0 * randn_like(x))."""
+    sac = sch["sqrt_alphas_cumprod"]
+    s1m = sch["sqrt_one_minus_alphas_cumprod"]
+    if t_index == 0:
+        return x0_pred / sac[t_index]
+    sigma = 0
+    return (sac[t_index - 1]) * x0_pred + (
+        torch.sqrt(1 - sac[t_index - 1] ** 2 - sigma ** 2) * (x - sac[t_index] * x0_pred) / s1m[t_index])
+
+
 def reverse_step(params, hp, sch, sampler: str, x: Tensor, spec_c: Optional[Tensor],
                  t_index: int, z: Optional[Tensor], w: float = 0.0,
                  table: Optional[Tensor] = None) -> Tensor:
@@ -286,6 +322,17 @@ def reverse_step(params, hp, sch, sampler: str, x: Tensor, spec_c: Optional[Tens
         x0 = denoise(params, hp, x, spec_u, t, table)         # :979-980
     elif sampler == "ddpm_x0":
         x0 = denoise(params, hp, x, spec_c, t, table)         # :839
+    elif sampler == "ddim_x0":
+        return ddim_x0_update(sch, x, denoise(params, hp, x, spec_c, t, table), t_index)      # :863
+    elif sampler == "cfdg_ddim_x0":
+        # :1039-1041.  NB the "unconditional" branch is forward(zeros_like(waveform)) WITHOUT
+        # sampling=True: the spectrogram of silence normalises to NaN -> 0 (model/utils.py:29-31),
+        # i.e. spec == 0 everywhere, not -1.
+        x0_c = denoise(params, hp, x, spec_c, t, table)
+        x0_z = denoise(params, hp, x, torch.zeros_like(spec_c), t, table)
+        return ddim_x0_update(sch, x, (1 + w) * x0_c - w * x0_z, t_index)
+    elif sampler in ("ddpm", "ddim", "ddim2ddpm"):
+        return eps_update(sch, sampler, x, denoise(params, hp, x, spec_c, t, table), t_index, z)
     else:
         raise ValueError(sampler)
     return posterior_update(sch, x, x0, t_index, z)

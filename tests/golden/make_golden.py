@@ -148,10 +148,41 @@ def gen_steps_and_chain():
     save("steps_chain_k9", **arrays)
 
 
+def gen_extra_samplers():
+    """ddim_x0, cfdg_ddim_x0 and the epsilon-prediction samplers ddpm / ddim / ddim2ddpm."""
+    S = 8
+    hp = hp_small(9, C=32, L=5, S=S)
+    params = R.synthetic_params(hp, seed=556)
+    B, T = 2, 24
+    torch.manual_seed(43)
+    wav = 0.1 * torch.randn(B, T * 512)
+    x = torch.randn(B, 1, T, 88)
+    noise = torch.randn(S, B, 1, T, 88)
+    arrays = dict(hp=json.dumps(hp), seed=556, wsum=weight_checksum(params), wav=wav, x=x, noise=noise, w=0.5)
+    for sampler in ("ddim_x0", "cfdg_ddim_x0", "ddpm", "ddim", "ddim2ddpm"):
+        m = RI.build_reference(hp, sampler, 0.5)
+        RI.load_params(m, params)
+        with torch.no_grad():
+            for t_index in (S - 1, 1, 0):
+                with RI.injected_noise([noise[t_index]]):
+                    out, _ = m.reverse_diffusion(x, wav, t_index)
+                arrays[f"{sampler}_t{t_index}"] = out
+            xx = x
+            with RI.injected_noise([noise[t] for t in reversed(range(1, S))]):
+                for t_index in reversed(range(S)):
+                    xx, _ = m.reverse_diffusion(xx, wav, t_index)
+            arrays[f"{sampler}_chain"] = xx
+    save("steps_chain_extra_k9", **arrays)
+
+
 if __name__ == "__main__":
     assert RI.reference_available(), "needs /root/reference"
     torch.set_num_threads(8)
+    if "--extra-only" in sys.argv:
+        gen_extra_samplers()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
     gen_steps_and_chain()
+    gen_extra_samplers()

@@ -122,6 +122,23 @@ def test_steps_and_chain_golden(golden_dir, sampler):
         assert d <= ATOL_STEP, (use_graph, d)
 
 
+@pytest.mark.parametrize("sampler", ["ddim_x0", "cfdg_ddim_x0", "ddpm", "ddim", "ddim2ddpm"])
+def test_extra_samplers_golden(golden_dir, sampler):
+    """the remaining samplers against vectors produced by the reference."""
+    g = load(golden_dir, "steps_chain_extra_k9")
+    hp, p, m = fixture_model(g, sampler=sampler, w=float(g["w"]))
+    S = hp["timesteps"]
+    x, wav, noise = T(g["x"]), T(g["wav"]), T(g["noise"])
+    for t_index in (S - 1, 1, 0):
+        out, spec = m.reverse_diffusion(x, wav, t_index, noise=noise[t_index])
+        d = maxdiff(out.cpu(), g[f"{sampler}_t{t_index}"])
+        assert d <= ATOL_STEP, (t_index, d)
+    for use_graph in (False, True):
+        roll, _ = m.sample(x, wav, noise=noise, use_graph=use_graph)
+        d = maxdiff(roll.cpu(), g[f"{sampler}_chain"])
+        assert d <= ATOL_STEP, (use_graph, d)
+
+
 # --------------------------------------------------------------------------------------------
 # full-size network (k=9, C=512, 15 layers) against the oracle
 # --------------------------------------------------------------------------------------------

@@ -45,6 +45,41 @@ def test_posterior_coef_table_reproduces_the_update():
         assert torch.equal(mine, ref), t
 
 
+def test_sampler_coef_tables_reproduce_every_update():
+    """(5,S,5) coefficient families (DR_COEF_*) fed through the update kernel's formulas equal the oracle's
+    updates (task/diffusion.py:804-911, :957-967) bit for bit on CPU."""
+    from diffroll_amd.schedule import make_schedule, sampler_coef_tables
+    S = 50
+    sch = make_schedule(1e-4, 0.02, S)
+    coef = sampler_coef_tables(sch)
+    assert coef.shape == (5, S, 5)
+    osch = R.schedule(1e-4, 0.02, S)
+    torch.manual_seed(1)
+    x, y, z = torch.randn(2, 1, 5, 88), torch.randn(2, 1, 5, 88), torch.randn(2, 1, 5, 88)
+    for t in (S - 1, 17, 1, 0):
+        c = coef[:, t]
+        # family 1: ddim_x0
+        ref = R.ddim_x0_update(osch, x, y, t)
+        mine = y / c[1][2] if t == 0 else c[1][0] * y + (c[1][1] * (x - c[1][2] * y)) / c[1][3]
+        assert torch.equal(mine, ref), ("ddim_x0", t)
+        # family 2: eps ddpm
+        ref = R.eps_update(osch, "ddpm", x, y, t, z)
+        m = c[2][0] * (x - (c[2][1] * y) / c[2][2])
+        mine = m if t == 0 else m + c[2][3] * z
+        assert torch.equal(mine, ref), ("ddpm", t)
+        # families 3/4: eps ddim / ddim2ddpm
+        for fam, name in ((3, "ddim"), (4, "ddim2ddpm")):
+            ref = R.eps_update(osch, name, x, y, t, z)
+            xe = (x - c[fam][3] * y) / c[fam][2]
+            if t == 0:
+                mine = xe
+            elif fam == 3:
+                mine = c[fam][0] * xe + c[fam][1] * y
+            else:
+                mine = (c[fam][0] * xe + c[fam][1] * y) + c[fam][4] * z
+            assert torch.equal(mine, ref), (name, t)
+
+
 def make(**kw):
     from diffroll_amd import ClassifierFreeDiffRoll
     args = dict(residual_channels=32, unconditional=False, condition="fixed", n_mels=229,
@@ -86,10 +121,10 @@ def test_hparams_and_error_behaviour():
         make(condition="trainable_z")
     with pytest.raises(AttributeError):
         make(sampling={"type": "no_such_sampler"})   # getattr at task/diffusion.py:255
-    with pytest.raises(NotImplementedError):
-        make(sampling={"type": "ddim_x0"})
-    for s in ("ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0"):
-        assert make(sampling={"type": s, "w": 0.1}).reverse_diffusion is not None
+    for s in ("ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0", "ddim_x0", "cfdg_ddim_x0", "ddpm", "ddim",
+              "ddim2ddpm"):
+        m2 = make(sampling={"type": s, "w": 0.1})
+        assert m2.reverse_diffusion.__func__ is getattr(type(m2), s)
 
 
 def test_mask_ranges_follow_python_slicing():

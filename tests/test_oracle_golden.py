@@ -92,3 +92,21 @@ def test_steps_and_chain(golden_dir, sampler):
             assert np.allclose(out.numpy(), g[f"{sampler}_t{t_index}"], atol=ATOL), t_index
         final = R.sample_chain(p, hp, sampler, x, wav, noise, w, inpainting_t=it)
     assert np.allclose(final.numpy(), g[f"{sampler}_chain"], atol=ATOL)
+
+
+@pytest.mark.parametrize("sampler", ["ddim_x0", "cfdg_ddim_x0", "ddpm", "ddim", "ddim2ddpm"])
+def test_extra_samplers_steps_and_chain(golden_dir, sampler):
+    """SURVEY 8f-3 samplers against the reference's own outputs."""
+    g = load(golden_dir, "steps_chain_extra_k9")
+    hp, p = params_for(g)
+    S = hp["timesteps"]
+    x, wav, noise = T(g["x"]), T(g["wav"]), T(g["noise"])
+    w = float(g["w"])
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], S)
+    spec_c = R.frontend(wav, hp, x.shape[2])
+    with torch.no_grad():
+        for t_index in (S - 1, 1, 0):
+            out = R.reverse_step(p, hp, sch, sampler, x, spec_c, t_index, noise[t_index], w)
+            assert np.allclose(out.numpy(), g[f"{sampler}_t{t_index}"], atol=ATOL), t_index
+        final = R.sample_chain(p, hp, sampler, x, wav, noise, w)
+    assert np.allclose(final.numpy(), g[f"{sampler}_chain"], atol=ATOL)
