@@ -80,6 +80,7 @@ struct dr_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     long long* dbg_ticks = nullptr;     // dr_bench_layer measurement hook
+    unsigned long long* d_counts = nullptr;   // dr_frame_counts accumulator
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
 
     // profiling of the dominant kernel
@@ -411,6 +412,7 @@ void dr_destroy(dr_engine* e) {
     if (e->graph) (void)hipGraphDestroy(e->graph);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
+    if (e->d_counts) (void)hipFree(e->d_counts);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
@@ -756,6 +758,25 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         e->gkey = key;
     }
     HIPCHK(e, hipGraphLaunch(e->gexec, st));
+    return DR_OK;
+}
+
+int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, size_t n, float threshold,
+                    int64_t* host_counts, void* stream) {
+    if (!e || !d_pred || !d_label || !host_counts) return fail(e, DR_EINVAL, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    if (!e->d_counts) {
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, 3 * sizeof(unsigned long long)));
+        e->d_counts = (unsigned long long*)q;
+    }
+    HIPCHK(e, hipMemsetAsync(e->d_counts, 0, 3 * sizeof(unsigned long long), st));
+    HIPCHK(e, launch_frame_counts(d_pred, d_label, threshold, (long)n, e->d_counts, st));
+    unsigned long long h[3];
+    HIPCHK(e, hipMemcpyAsync(h, e->d_counts, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    for (int i = 0; i < 3; ++i) host_counts[i] = (int64_t)h[i];
     return DR_OK;
 }
 

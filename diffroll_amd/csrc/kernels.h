@@ -98,5 +98,8 @@ hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4,
                             int B, int planes_in, int planes_out, int TF, int T, int n_rows,
                             int mt0, int mt1, int mf0, int mf1, hipStream_t s);
 hipError_t launch_fill(float* p, float v, long n, hipStream_t s);
+// counts[0..2] += {TP, FP, FN} of (pred > thr) against (label > 0.5) over n elements (exact integers)
+hipError_t launch_frame_counts(const float* pred, const float* label, float thr, long n,
+                               unsigned long long* counts, hipStream_t s);
 
 }  // namespace dr

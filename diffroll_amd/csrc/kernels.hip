@@ -706,4 +706,35 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Frame-level confusion counts of task/diffusion.py:381-383 (sklearn precision_recall_fscore_support,
+// average='binary', on label.flatten() vs pred.flatten() > threshold): HBM-bound, 8 B per element,
+// integer-exact (per-lane counters -> wave shuffles -> one 64-bit atomic per wave), so the metric does
+// not depend on launch geometry.
+__global__ __launch_bounds__(256) void frame_counts_kernel(const float* __restrict__ pred,
+                                                           const float* __restrict__ label, float thr, long n,
+                                                           unsigned long long* counts) {
+    unsigned tp = 0, fp = 0, fn = 0;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const bool p = pred[i] > thr, l = label[i] > 0.5f;
+        tp += (p && l); fp += (p && !l); fn += (!p && l);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        tp += __shfl_xor(tp, off); fp += __shfl_xor(fp, off); fn += __shfl_xor(fn, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)tp);
+        atomicAdd(&counts[1], (unsigned long long)fp);
+        atomicAdd(&counts[2], (unsigned long long)fn);
+    }
+}
+hipError_t launch_frame_counts(const float* pred, const float* label, float thr, long n,
+                               unsigned long long* counts, hipStream_t s) {
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(frame_counts_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256),
+                       0, s, pred, label, thr, n, counts);
+    return hipGetLastError();
+}
+
 }  // namespace dr

@@ -164,6 +164,17 @@ class Engine:
                                            self._stream()))
         return x
 
+    def frame_counts(self, pred: torch.Tensor, label: torch.Tensor, threshold: float) -> Tuple[int, int, int]:
+        """(TP, FP, FN) of pred > threshold vs the binary label roll (any equal shapes)."""
+        p = self._dev(pred)
+        l = self._dev(label)
+        assert p.numel() == l.numel()
+        out = (C.c_int64 * 3)()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_frame_counts(self.h, p.data_ptr(), l.data_ptr(), p.numel(), float(threshold), out,
+                                                 self._stream()))
+        return int(out[0]), int(out[1]), int(out[2])
+
     # ------------------------------------------------------------------ measurement helpers
     def profile_enable(self, on: bool):
         self._check(self.lib.dr_profile_enable(self.h, 1 if on else 0))

@@ -348,6 +348,29 @@ class ClassifierFreeDiffRoll(nn.Module):
         roll, _ = self.sample(noise, waveform, seed=batch_idx)
         return roll
 
+    @staticmethod
+    def frame_metrics(tp: int, fp: int, fn: int) -> Tuple[float, float, float]:
+        """precision / recall / F1 from the confusion counts with sklearn's average='binary'
+        conventions (0 where a denominator is 0)."""
+        p = tp / (tp + fp) if tp + fp > 0 else 0.0
+        r = tp / (tp + fn) if tp + fn > 0 else 0.0
+        f = 2 * p * r / (p + r) if p + r > 0 else 0.0
+        return p, r, f
+
+    def test_step(self, batch, batch_idx=0):
+        """Frame-level part of task/diffusion.py:312-428: sample the batch, threshold the final roll at
+        hparams.frame_threshold and score it against batch['frame'] exactly as
+        sklearn.metrics.precision_recall_fscore_support(label.flatten(), pred.flatten() > thr,
+        average='binary') does (:381-383).  Returns the metrics the reference logs per batch
+        (note-level F1 via mir_eval is host-side post-processing and out of scope)."""
+        roll, _ = self.sampling(batch, batch_idx)
+        label = batch["frame"]
+        Tm = roll.shape[2]
+        tp, fp, fn = self.engine.frame_counts(roll[:, 0], label[:, :Tm].to(roll.device, torch.float32),
+                                              float(self.hparams.frame_threshold))
+        p, r, f = self.frame_metrics(tp, fp, fn)
+        return {"Test/Frame_F1": f, "Test/Frame_precision": p, "Test/Frame_recall": r, "tp": tp, "fp": fp, "fn": fn}
+
     def sampling(self, batch, batch_idx=0):
         """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""
         frame = batch["frame"]

@@ -168,6 +168,15 @@ int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, 
 int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T,
               float w, uint64_t seed, int first_sample, int use_graph, void* stream);
 
+/*
+ * Frame-level evaluation of test_step (task/diffusion.py:381-383): confusion counts of
+ * (d_pred > threshold) against the binary label roll over n elements, the integers sklearn's
+ * precision_recall_fscore_support(average='binary') is computed from.  host_counts = {TP, FP, FN}.
+ * Synchronises `stream`.
+ */
+int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, size_t n, float threshold,
+                    int64_t* host_counts, void* stream);
+
 /* Timing of the dominant kernel (dilated conv + gate) inside dr_sample, measured with HIP events
  * on the launch stream when enabled: returns launches and total milliseconds since last reset. */
 int dr_profile_enable(dr_engine* e, int on);

@@ -264,3 +264,29 @@ def test_philox_noise_is_standard_normal(full_model):
     assert abs(float(z.std()) - 1.0) < 0.02
     assert abs(float((z ** 3).mean())) < 0.05
     assert abs(float((z ** 4).mean()) - 3.0) < 0.15
+
+
+def test_frame_f1_matches_sklearn(full_model):
+    """frame P/R/F1 of test_step (task/diffusion.py:381-383) = sklearn's binary
+    precision_recall_fscore_support on the thresholded roll; counts are integer-exact."""
+    from sklearn.metrics import precision_recall_fscore_support
+    hp, p, m = full_model
+    torch.manual_seed(3)
+    B, Tn = 5, 125
+    pred = torch.rand(B, 1, Tn, 88) * 1.4 - 0.2
+    label = (torch.rand(B, Tn, 88) > 0.9).float()
+    for thr in (0.5, 0.8):
+        tp, fp, fn = m.engine.frame_counts(pred[:, 0], label, thr)
+        pb = (pred.flatten() > thr).numpy()
+        lb = label.flatten().numpy()
+        assert tp == int((pb & (lb > 0.5)).sum()) and fp == int((pb & ~(lb > 0.5)).sum())
+        assert fn == int((~pb & (lb > 0.5)).sum())
+        sp, sr, sf, _ = precision_recall_fscore_support(lb, pb, average="binary")
+        mp, mr, mf = m.frame_metrics(tp, fp, fn)
+        assert abs(mp - sp) < 1e-12 and abs(mr - sr) < 1e-12 and abs(mf - sf) < 1e-12
+    assert m.frame_metrics(0, 0, 0) == (0.0, 0.0, 0.0)
+    # end to end: test_step on a batch (label normalisation is irrelevant for the metric)
+    m2 = make_model(hp, p, sampler="ddim_x0")
+    wav = 0.1 * torch.randn(2, 64000)
+    out = m2.test_step({"frame": label[:2], "audio": wav}, 0)
+    assert 0.0 <= out["Test/Frame_F1"] <= 1.0 and out["tp"] + out["fn"] == int(label[:2].sum())
