@@ -25,6 +25,8 @@ struct LayerW {
     float* conv_b = nullptr;     // packed-row bias (conditional samples; cond tensor carries bc)
     float* conv_b_u = nullptr;   // packed-row bias for unconditional samples: b_conv + (bc - sum_m Wc)
     float* conv_b_z = nullptr;   // ... for spec == 0 samples (cfdg_ddim_x0's second branch): b_conv + bc
+    float* conv_w3 = nullptr;    // split-bf16 ("S3") packing of conv_w  [MTc][kch][k] slabs of 24 KiB
+    float* out_w3 = nullptr;     // split-bf16 packing of out_w
     float* out_w = nullptr;      // packed (natural halves) 1x1
     float* out_b = nullptr;
     float* cond_w = nullptr;     // packed (paired rows) conditioner 1x1
@@ -66,6 +68,8 @@ struct dr_engine {
     // activation workspace (sized for ws_NB samples x ws_T frames)
     int ws_NB = 0, ws_T = 0;
     float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
+    float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
+    int prec = 0;                          // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3, 6 products)
     // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
     int fe_B = 0, fe_T = 0;
     size_t cond_cap = 0;
@@ -130,6 +134,41 @@ std::vector<float> pack_weights(int MT, int kchunks, int taps, F get) {
     return out;
 }
 
+// split-bf16 packing: [mtile][kchunk32][tap][g16 = 2][piece = 3][kq = 2][row = 128][8 bf16]
+inline uint16_t bf16_rne(float x) {
+    uint32_t v;
+    memcpy(&v, &x, 4);
+    return (uint16_t)((v + 0x7FFFu + ((v >> 16) & 1u)) >> 16);
+}
+inline float bf16_to_f32(uint16_t b) {
+    const uint32_t v = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+template <class F>
+std::vector<uint16_t> pack_weights_s3(int MT, int kchunks, int taps, F get) {
+    std::vector<uint16_t> out((size_t)MT * kchunks * taps * 12288);
+    size_t slab = 0;
+    for (int mt = 0; mt < MT; ++mt)
+        for (int kc = 0; kc < kchunks; ++kc)
+            for (int j = 0; j < taps; ++j, ++slab)
+                for (int g = 0; g < 2; ++g)
+                    for (int kq = 0; kq < 2; ++kq)
+                        for (int row = 0; row < 128; ++row)
+                            for (int i = 0; i < 8; ++i) {
+                                const float w = get(mt * 128 + row, kc * 32 + g * 16 + kq * 8 + i, j);
+                                const uint16_t p0 = bf16_rne(w);
+                                const float r1 = w - bf16_to_f32(p0);
+                                const uint16_t p1 = bf16_rne(r1);
+                                const uint16_t p2 = bf16_rne(r1 - bf16_to_f32(p1));
+                                const uint16_t pc[3] = {p0, p1, p2};
+                                for (int pz = 0; pz < 3; ++pz)
+                                    out[slab * 12288 + ((((size_t)g * 3 + pz) * 2 + kq) * 128 + row) * 8 + i] = pc[pz];
+                            }
+    return out;
+}
+
 // paired row map: packed row -> (which half mi, channel c); 128-row tile = 2 wave-rows x {gate32, filter32}
 inline void paired_row(int prow, int& mi, int& c) {
     const int mt = prow >> 7, rr = prow & 127;
@@ -143,6 +182,15 @@ int upload(dr_engine* e, const std::vector<float>& v, float** out) {
     HIPCHK(e, hipMalloc(&p, std::max<size_t>(v.size(), 4) * sizeof(float)));
     e->owned.push_back(p);
     HIPCHK(e, hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)p;
+    return DR_OK;
+}
+
+int upload_bytes(dr_engine* e, const void* data, size_t bytes, float** out) {
+    void* p = nullptr;
+    HIPCHK(e, hipMalloc(&p, std::max<size_t>(bytes, 16)));
+    e->owned.push_back(p);
+    HIPCHK(e, hipMemcpy(p, data, bytes, hipMemcpyHostToDevice));
     *out = (float*)p;
     return DR_OK;
 }
@@ -230,6 +278,8 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     int rc;
     if ((rc = dev_alloc(e, &e->h, act))) return rc;
     if ((rc = dev_alloc(e, &e->hd, act))) return rc;
+    if ((rc = dev_alloc(e, &e->hd3, act + act / 2))) return rc;
+    if ((rc = dev_alloc(e, &e->g3, act + act / 2))) return rc;
     if ((rc = dev_alloc(e, &e->g, act))) return rc;
     if ((rc = dev_alloc(e, &e->skip, act))) return rc;
     if ((rc = dev_alloc(e, &e->tmp, act))) return rc;
@@ -248,6 +298,13 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
 int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, int T, int t, float* x0_out,
                 hipStream_t st, bool zero_spec = false) {
     const int Cp = e->Cp, P = Cp / 4, L = e->L;
+    const int prec = e->prec;
+    const long act_bs = (long)Cp * T, s3_bs = act_bs + act_bs / 2;   // per-sample sizes (4-byte units)
+    // S3 input description of an activation tensor with Cp channels
+    auto s3_in = [&](GemmArgs& a, const float* X) {
+        a.X = X; a.x_bs = s3_bs; a.x_piece = (long)(Cp / 8) * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4;
+        a.x_planes = Cp / 8; a.kchunks = Cp / 32;
+    };
     // input projection + relu (model/diffwave.py:667-668)
     {
         GemmArgs a{};
@@ -255,30 +312,40 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
         a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
         p4_out(a, e->h, P, T, Cp);
-        a.Y2 = e->hd; a.d2 = e->d_dtab + (size_t)t * L * Cp;     // hd = h + d_0 (model/diffwave.py:138-139)
+        // hd = h + d_0 (model/diffwave.py:138-139), fp32 P4 or split-bf16 for the first dilated conv
+        a.d2 = e->d_dtab + (size_t)t * L * Cp;
+        if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
+        else { a.Y2 = e->hd; a.y2_bs = act_bs; }
         HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
     }
     for (int l = 0; l < L; ++l) {
         const LayerW& w = e->layers[l];
         {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
-            GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
+            GemmArgs a = p4_gemm(prec ? w.conv_w3 : w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
+            if (prec) s3_in(a, e->hd3);
             a.bias2 = zero_spec ? w.conv_b_z : w.conv_b_u;   // samples >= n_cond: spec == 0 or spec == -1
             a.taps = e->K; a.dil = w.dil;
             a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
             a.c_bs = (long)2 * Cp * T;
             a.n_cond = n_cond;
             p4_out(a, e->g, P, T, Cp);
+            if (prec) { a.Y = e->g3; a.y_bs = s3_bs; a.out_s3 = 1; }
             const bool timed = e->prof && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), st));
+            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), st, prec));
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
         }
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
-            GemmArgs a = p4_gemm(w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+            GemmArgs a = p4_gemm(prec ? w.out_w3 : w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+            if (prec) s3_in(a, e->g3);
             p4_out(a, e->h, P, T, Cp);
-            if (l + 1 < L) { a.Y2 = e->hd; a.d2 = e->d_dtab + ((size_t)t * L + l + 1) * Cp; }
+            if (l + 1 < L) {
+                a.d2 = e->d_dtab + ((size_t)t * L + l + 1) * Cp;
+                if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
+                else { a.Y2 = e->hd; a.y2_bs = act_bs; }
+            }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
-            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, pick_ni(Cp / 64, NB, T, 1, 1), st));
+            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, prec ? 1 : pick_ni(Cp / 64, NB, T, 1, 1), st, prec));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
@@ -415,7 +482,7 @@ void dr_destroy(dr_engine* e) {
     if (e->d_counts) (void)hipFree(e->d_counts);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
-    float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
+    float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
                      e->wav_pad, e->power, e->logmel, e->specP4, e->mm};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
@@ -518,6 +585,19 @@ int dr_commit(dr_engine* e, void* stream) {
         for (int pr = 0; pr < 2 * Cp; ++pr) {
             const int half = pr >= Cp, c = pr - half * Cp;
             if (c < C) bout[pr] = Bo[half * C + c];
+        }
+        {   // split-bf16 packings of the two hot GEMMs (same row maps, same zero padding)
+            auto pconv3 = pack_weights_s3(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
+                int mi, c; paired_row(pr, mi, c);
+                return (c < C && ch < C) ? Wd[((size_t)(mi * C + c) * C + ch) * K + j] : 0.f;
+            });
+            auto pout3 = pack_weights_s3(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
+                const int half = pr >= Cp, c = pr - half * Cp;
+                return (c < C && ch < C) ? Wo[(size_t)(half * C + c) * C + ch] : 0.f;
+            });
+            if ((rc = upload_bytes(e, pconv3.data(), pconv3.size() * 2, &lw.conv_w3)) ||
+                (rc = upload_bytes(e, pout3.data(), pout3.size() * 2, &lw.out_w3)))
+                return rc;
         }
         if ((rc = upload(e, pconv, &lw.conv_w)) || (rc = upload(e, bconv, &lw.conv_b)) ||
             (rc = upload(e, bconv_u, &lw.conv_b_u)) || (rc = upload(e, bconv_z, &lw.conv_b_z)) ||
@@ -819,7 +899,12 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
     const LayerW& w = e->layers[layer];
-    GemmArgs a = p4_gemm(w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
+    GemmArgs a = p4_gemm(e->prec ? w.conv_w3 : w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
+    const long act_bs = (long)Cp * T, s3_bs = act_bs + act_bs / 2;
+    if (e->prec) {
+        a.X = e->hd3; a.x_bs = s3_bs; a.x_piece = (long)(Cp / 8) * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4;
+        a.x_planes = Cp / 8; a.kchunks = Cp / 32;
+    }
     a.bias2 = w.conv_b_u;
     a.taps = e->K; a.dil = w.dil;
     (void)t;
@@ -827,6 +912,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     a.c_bs = (long)2 * Cp * T;
     a.n_cond = n_cond;
     p4_out(a, e->g, P, T, Cp);
+    if (e->prec) { a.Y = e->g3; a.y_bs = s3_bs; a.out_s3 = 1; }
     if (!e->dbg_ticks) {
         void* q = nullptr;
         HIPCHK(e, hipMalloc(&q, 16 * sizeof(long long)));
@@ -834,7 +920,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), (hipStream_t)stream));
+    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
 
@@ -846,7 +932,12 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
     const LayerW& w = e->layers[layer];
-    GemmArgs a = p4_gemm(w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+    GemmArgs a = p4_gemm(e->prec ? w.out_w3 : w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
+    if (e->prec) {
+        const long act_bs = (long)Cp * T;
+        a.X = e->g3; a.x_bs = act_bs + act_bs / 2; a.x_piece = (long)(Cp / 8) * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4;
+        a.x_planes = Cp / 8; a.kchunks = Cp / 32;
+    }
     p4_out(a, e->h, P, T, Cp);
     a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = 0;
     if (!e->dbg_ticks) {
@@ -856,7 +947,20 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, pick_ni(Cp / 64, NB, T, 1, 1), (hipStream_t)stream));
+    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, e->prec ? 1 : pick_ni(Cp / 64, NB, T, 1, 1), (hipStream_t)stream, e->prec));
+    return DR_OK;
+}
+
+int dr_set_precision(dr_engine* e, int mode) {
+    if (!e) return DR_EINVAL;
+    if (mode != DR_PRECISION_F32 && mode != DR_PRECISION_BF16X3) return fail(e, DR_EINVAL, "unknown precision mode %d", mode);
+    if (mode != e->prec) {
+        (void)hipDeviceSynchronize();
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        e->gkey = GraphKey{};
+        e->prec = mode;
+    }
     return DR_OK;
 }
 

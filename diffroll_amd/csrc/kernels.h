@@ -42,6 +42,7 @@ struct GemmArgs {
     // B operand
     const float* X;
     long x_bs, x_ps, x_fs;   // batch / plane / frame strides in floats
+    long x_piece;            // S3 input only: stride between the three bf16 pieces (4-byte units)
     int x_planes;            // valid planes (Cin/4); planes beyond re-read the last one (their weights are zero)
     int x_bmod;              // sample index is taken modulo this (0 = no modulo)
     int NB, T;               // samples, frames per sample
@@ -51,6 +52,8 @@ struct GemmArgs {
     // output
     float* Y;
     long y_bs, y_ps, y_fs;
+    long y2_bs;              // batch stride of Y2 (4-byte units)
+    int out_s3;              // bit 0: Y (EPI_GATE) is written in S3 split-bf16 layout; bit 1: Y2 is
     float* Y2;               // EPI_RELU / residual rows of EPI_RES_SKIP: optional second output Y2 = Y + d2[row]
                              // (same strides): the (h + step embedding) tensor the next dilated conv reads
     const float* d2;         // [>= y_rows] never null (zero vector when unused)
@@ -70,8 +73,9 @@ struct GemmArgs {
 
 // NI = N sub-tiles of 32 frames per wave: block tile = 128 rows x (64*NI) frames, 256 threads.
 hipError_t init_kernels();
-hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s);
-size_t gemm_lds_bytes(int NI, int KS, int taps, int dil);
+// prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
+hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec);
 int gemm_max_halo(int NI);
 
 struct UpdateArgs {

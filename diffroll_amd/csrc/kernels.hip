@@ -30,6 +30,48 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 struct A8 { float4 v[8]; };                          // A fragments of one K step: [group g][row tile mi]
+struct A12 { uint4 v[12]; };                         // split-bf16 A fragments of one K step: [(g*3 + piece)*2 + mi]
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---------------------------------------------------------------------------------------------
+// "S3" split precision: an fp32 value x is carried as three bf16 pieces x = p0 + p1 + p2 (each the
+// round-to-nearest-even bf16 of the remaining residual; 3 x 8 significant bits reconstruct the 24-bit
+// fp32 significand EXACTLY).  A product a*b is formed from the six piece products with i + j <= 2
+// (dropping terms <= 2^-24 |ab|, i.e. one fp32 ulp) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+// measured dot-product error is below that of a plain fp32 FMA chain, at 16/6 = 2.67x the matrix rate
+// of v_mfma_f32_32x32x2_f32.  S3 tensor layout: [batch][piece 3][plane8 = channel/8][frame][8 bf16].
+// ---------------------------------------------------------------------------------------------
+DR_DEVINL uint32_t bf16_rne_bits(float x) {          // fp32 bits of bf16(x) (low 16 bits zero)
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+DR_DEVINL void split3(float x, uint32_t (&pc)[3]) {
+    pc[0] = bf16_rne_bits(x);
+    const float r1 = x - __uint_as_float(pc[0]);     // exact
+    pc[1] = bf16_rne_bits(r1);
+    const float r2 = r1 - __uint_as_float(pc[1]);    // exact
+    pc[2] = bf16_rne_bits(r2);
+}
+// store 4 consecutive channels (one C/D register quad) of frame t as the three bf16 pieces:
+// dst = S3 tensor base of this sample; the quad is the low (half = 0) or high 8 bytes of its plane8 unit
+DR_DEVINL void store_s3_quad(float* dst, const float (&v)[4], int row0, int t, int T, int P8) {
+    uint32_t pc[4][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split3(v[e], pc[e]);
+    const long plane8 = row0 >> 3;
+    const int half = (row0 >> 2) & 1;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        uint2 w;
+        w.x = (pc[0][p] >> 16) | pc[1][p];
+        w.y = (pc[2][p] >> 16) | pc[3][p];
+        char* q = reinterpret_cast<char*>(dst) + (((long)p * P8 + plane8) * T + t) * 16 + half * 8;
+        *reinterpret_cast<uint2*>(q) = w;
+    }
+}
+DR_DEVINL f32x16 mma_bf16(const uint4 a, const uint4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 
 // sched_group_barrier helpers (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read): NV times
 // {GAP MFMAs, 1 VMEM read}, ND times {GAP MFMAs, 1 DS read}, then REM MFMAs.
@@ -78,12 +120,15 @@ DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 //   the dilated conv read it at shifted frame offsets with conflict-free ds_read_b128.
 //   K loop: for chunk (32*KS input channels) for tap for sub-chunk: 64*NI MFMAs per consumer wave.
 // ---------------------------------------------------------------------------------------------
-template <int NI, int KS, int EPI>
+//   PREC = 1 ("S3"): the X input and the weights are split-bf16 (see above): X tile rows are
+//   [(sub*2 + g)*6 + piece*2 + kq] (16 channels per group g, 8 per kq half), the consumers run 6
+//   v_mfma_f32_32x32x16_bf16 per (group, row tile, frame tile) instead of 8 fp32 MFMAs per 16 channels.
+template <int NI, int KS, int EPI, int PREC>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 64 * NI;
     constexpr int WN = 32 * NI;
-    constexpr int XP = 8 * KS;      // planes per X tile
+    constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,9 +181,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 const int pl = i / wl, seg = i - pl * wl;
                 const int f = seg * 64 + lane;
                 // planes beyond Cin (K padding) re-read the last valid plane: finite data x zero weights
-                const int pc = min(chunk * XP + pl, last_plane);
-                const __amdgpu_buffer_rsrc_t rsrc =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(Xg + (long)pc * a.x_ps), 0, recs, 0x00020000);
+                const float* src;
+                if constexpr (PREC) {
+                    const int sg = pl / 6, rem = pl - sg * 6, pce = rem >> 1, kq = rem & 1;
+                    const int pc = min(chunk * (4 * KS) + sg * 2 + kq, last_plane);       // plane8
+                    src = Xg + (long)pce * a.x_piece + (long)pc * a.x_ps;
+                } else {
+                    src = Xg + (long)min(chunk * XP + pl, last_plane) * a.x_ps;
+                }
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
                 float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
@@ -162,8 +213,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // ---------------------------------------------------------------------- consumers
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 31, hi = lane >> 5;
-    // this lane's A fragments inside a 16-KiB slab: [g][hi][row][4]
-    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024 + hi * 128 + wr * 64 + r;
+    // this lane's A fragments inside a slab: fp32 [g][hi][row][4] (16 KiB); S3 [g16][piece][kq][row][8 bf16] (24 KiB)
+    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * (PREC ? 1536 : 1024) + hi * 128 + wr * 64 + r;
 
     f32x16 acc[2][NI];
 #pragma unroll
@@ -198,6 +249,79 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         }
     }
 
+    if constexpr (PREC == 1) {
+        const uint4* Wg3 = reinterpret_cast<const uint4*>(Wg);
+        auto load_a3 = [&](int slab) -> A12 {
+            A12 o;
+            const uint4* src = Wg3 + (long)slab * 1536;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int pz = 0; pz < 3; ++pz)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) o.v[(g * 3 + pz) * 2 + mi] = src[(g * 3 + pz) * 256 + mi * 32];
+            return o;
+        };
+        A12 wA = load_a3(0), wB;
+        const int cen = (a.taps - 1) >> 1;
+        const uint4* Xs3 = reinterpret_cast<const uint4*>(Xs);
+        // one K step (32 channels x 1 tap): 2 groups x 6 piece products x 2 x NI tiles = 24*NI MFMAs per wave
+        auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
+            constexpr bool kB = decltype(ROLE)::value;
+            if constexpr (kB) wA = load_a3(min(slab + 1, NS - 1));
+            else wB = load_a3(min(slab + 1, NS - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            const uint4* Xb = Xs3 + ((chunk & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WN + r;
+            uint4 bf[2][3][NI];
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[0][pz][ni] = Xb[(pz * 2) * FW + ni * 32];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                if (g == 0) {
+#pragma unroll
+                    for (int pz = 0; pz < 3; ++pz)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) bf[1][pz][ni] = Xb[(6 + pz * 2) * FW + ni * 32];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const uint4 a0 = kB ? wB.v[(g * 3 + 0) * 2 + mi] : wA.v[(g * 3 + 0) * 2 + mi];
+                        const uint4 a1 = kB ? wB.v[(g * 3 + 1) * 2 + mi] : wA.v[(g * 3 + 1) * 2 + mi];
+                        const uint4 a2 = kB ? wB.v[(g * 3 + 2) * 2 + mi] : wA.v[(g * 3 + 2) * 2 + mi];
+                        // smallest terms first
+                        acc[mi][ni] = mma_bf16(a2, bf[g][0][ni], acc[mi][ni]);
+                        acc[mi][ni] = mma_bf16(a0, bf[g][2][ni], acc[mi][ni]);
+                        acc[mi][ni] = mma_bf16(a1, bf[g][1][ni], acc[mi][ni]);
+                        acc[mi][ni] = mma_bf16(a1, bf[g][0][ni], acc[mi][ni]);
+                        acc[mi][ni] = mma_bf16(a0, bf[g][1][ni], acc[mi][ni]);
+                        acc[mi][ni] = mma_bf16(a0, bf[g][0][ni], acc[mi][ni]);
+                    }
+            }
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        const int per_chunk = a.taps * KS;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            auto at = [&](auto R, int q) {
+                const int j = q / KS, sub = q - j * KS;
+                step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+            };
+            __syncthreads();
+            int q = 0;
+            for (; q + 2 <= per_chunk; q += 2) {
+                at(F_{}, q);
+                at(T_{}, q + 1);
+            }
+            if (q < per_chunk) {
+                at(F_{}, q);
+                wA = wB;
+            }
+        }
+    } else {
     auto load_a = [&](int slab) -> A8 {
         A8 o;
         const float4* src = Wg + (long)slab * 1024;
@@ -278,6 +402,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         }
     }
 
+    }
+
     const long long tick1 = a.dbg ? clock64() : 0;
     // ----------------------------------------------------------------------------------------
     // epilogue.  C/D fragment of 32x32: column = lane&31 (frame), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -348,8 +474,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
                 }
-                float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (a.out_s3 & 1) {   // g for the split-bf16 1x1 kernel
+                    store_s3_quad(a.Y + (long)b * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
+                } else {
+                    float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             } else {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
@@ -371,9 +501,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                             if (a.Y2) {        // hd = h + d_{l+1}: the next dilated conv's input (:139)
                                 float dd[4];
                                 f4arr(ed2[mi][q], dd);
-                                float* dst2 = a.Y2 + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                                *reinterpret_cast<float4*>(dst2) =
-                                    make_float4(o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]);
+                                const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                                if (a.out_s3 & 2) {
+                                    store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                } else {
+                                    float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                    *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                                }
                             }
                         } else {               // skip (+)= acc + b (:680)
                             float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
@@ -396,9 +530,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                             if (a.Y2) {    // hd = h + d_0 for the first dilated conv
                                 float dd[4];
                                 f4arr(ed2[mi][q], dd);
-                                float* dst2 = a.Y2 + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                                *reinterpret_cast<float4*>(dst2) =
-                                    make_float4(o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]);
+                                const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                                if (a.out_s3 & 2) {
+                                    store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                } else {
+                                    float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                    *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                                }
                             }
                         }
                     }
@@ -412,43 +550,44 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-size_t gemm_lds_bytes(int NI, int KS, int taps, int dil) {
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec) {
     const int halo = ((taps - 1) / 2) * dil;
     const int FW = 64 * NI + 2 * halo;
-    return (size_t)2 * 8 * KS * FW * 16;
+    return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16;
 }
 int gemm_max_halo(int NI) { return (256 - 64 * NI) / 2; }
 
-template <int NI, int KS, int EPI>
+template <int NI, int KS, int EPI, int PREC>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 64 * NI;
     const int tps = (a.T + BN - 1) / BN;
-    const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil);
+    const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil, PREC);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * tps;
     const dim3 grid((unsigned)(a.MT * NT));
     GemmArgs b = a;
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
     const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
-    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI>), grid, dim3(512), lds, s, b);
+    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
 }
 
-template <int NI, int KS, int EPI>
+template <int NI, int KS, int EPI, int PREC>
 static hipError_t init_gemm_t() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NI, KS, EPI>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NI, KS, EPI, PREC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <int NI, int KS>
 static hipError_t init_gemm_ni() {
     hipError_t e;
-    if ((e = init_gemm_t<NI, KS, EPI_PLAIN>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, KS, EPI_RELU>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, KS, EPI_SILU>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, KS, EPI_GATE>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, KS, EPI_RES_SKIP>()) != hipSuccess) return e;
-    if ((e = init_gemm_t<NI, KS, EPI_POWER>()) != hipSuccess) return e;
-    return init_gemm_t<NI, KS, EPI_LOG>();
+    if ((e = init_gemm_t<NI, KS, EPI_PLAIN, 0>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_RELU, 0>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_SILU, 0>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_GATE, 0>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_RES_SKIP, 0>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<NI, KS, EPI_POWER, 0>()) != hipSuccess) return e;
+    return init_gemm_t<NI, KS, EPI_LOG, 0>();
 }
 // allow > 64 KiB of dynamic LDS for every instantiation; call once per process before any launch
 // (and never inside a stream capture)
@@ -459,26 +598,37 @@ hipError_t init_kernels() {
     if ((e = init_gemm_ni<1, 2>()) != hipSuccess) return e;
     if ((e = init_gemm_ni<2, 2>()) != hipSuccess) return e;
     if ((e = init_gemm_ni<1, 4>()) != hipSuccess) return e;
-    return init_gemm_ni<2, 4>();
+    if ((e = init_gemm_ni<2, 4>()) != hipSuccess) return e;
+    // split-bf16 instantiations: dilated conv (KS = 1) and 1x1 (NI = 1: KS = 4)
+    if ((e = init_gemm_t<1, 1, EPI_GATE, 1>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
+    if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
+    return init_gemm_t<1, 1, EPI_RES_SKIP, 1>();
 }
 
 template <int NI, int KS>
 static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_PLAIN: return launch_gemm_t<NI, KS, EPI_PLAIN>(a, s);
-        case EPI_RELU: return launch_gemm_t<NI, KS, EPI_RELU>(a, s);
-        case EPI_SILU: return launch_gemm_t<NI, KS, EPI_SILU>(a, s);
-        case EPI_GATE: return launch_gemm_t<NI, KS, EPI_GATE>(a, s);
-        case EPI_RES_SKIP: return launch_gemm_t<NI, KS, EPI_RES_SKIP>(a, s);
-        case EPI_POWER: return launch_gemm_t<NI, KS, EPI_POWER>(a, s);
-        case EPI_LOG: return launch_gemm_t<NI, KS, EPI_LOG>(a, s);
+        case EPI_PLAIN: return launch_gemm_t<NI, KS, EPI_PLAIN, 0>(a, s);
+        case EPI_RELU: return launch_gemm_t<NI, KS, EPI_RELU, 0>(a, s);
+        case EPI_SILU: return launch_gemm_t<NI, KS, EPI_SILU, 0>(a, s);
+        case EPI_GATE: return launch_gemm_t<NI, KS, EPI_GATE, 0>(a, s);
+        case EPI_RES_SKIP: return launch_gemm_t<NI, KS, EPI_RES_SKIP, 0>(a, s);
+        case EPI_POWER: return launch_gemm_t<NI, KS, EPI_POWER, 0>(a, s);
+        case EPI_LOG: return launch_gemm_t<NI, KS, EPI_LOG, 0>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec) {
     const int halo = ((a.taps - 1) / 2) * a.dil;
     if (64 * NI + 2 * halo > 256 || a.kchunks < 1) return hipErrorInvalidValue;
+    if (prec == 1) {   // split-bf16 input: only the two hot kernels exist in this precision
+        if (epi == EPI_GATE) return NI == 1 ? launch_gemm_t<1, 1, EPI_GATE, 1>(a, s) : launch_gemm_t<2, 1, EPI_GATE, 1>(a, s);
+        if (epi == EPI_RES_SKIP && a.taps == 1)
+            return a.kchunks % 4 == 0 ? launch_gemm_t<1, 4, EPI_RES_SKIP, 1>(a, s) : launch_gemm_t<1, 1, EPI_RES_SKIP, 1>(a, s);
+        return hipErrorInvalidValue;
+    }
     // 1x1 GEMMs restage X every step: take up to 128 channels per chunk there (fewer hand-overs)
     const int KS = a.taps != 1 ? 1 : (a.kchunks % 4 == 0 ? 4 : (a.kchunks % 2 == 0 ? 2 : 1));
     if (NI == 1) {

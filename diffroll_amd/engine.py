@@ -68,6 +68,7 @@ class Engine:
             self.h, C.cast(self._tables[0].data_ptr(), C.POINTER(C.c_float)),
             C.cast(self._tables[1].data_ptr(), C.POINTER(C.c_float))))
         self.committed = False
+        self.precision = "f32"
         self._keep = []   # tensors referenced by a captured graph must stay alive
 
     # ------------------------------------------------------------------
@@ -174,6 +175,12 @@ class Engine:
             self._check(self.lib.dr_frame_counts(self.h, p.data_ptr(), l.data_ptr(), p.numel(), float(threshold), out,
                                                  self._stream()))
         return int(out[0]), int(out[1]), int(out[2])
+
+    def set_precision(self, mode: str):
+        """'f32' (default, exact fp32 MFMA) or 'bf16x3' (opt-in split-bf16: three bf16 pieces per operand,
+        six piece products, fp32 accumulation - fp32-level error at 2.67x the matrix rate)."""
+        self._check(self.lib.dr_set_precision(self.h, _cabi.PRECISIONS[mode]))
+        self.precision = mode
 
     # ------------------------------------------------------------------ measurement helpers
     def profile_enable(self, on: bool):

@@ -102,7 +102,8 @@ class ClassifierFreeDiffRoll(nn.Module):
                  sampling=None,
                  debug=False,
                  generation_filter=0.0,
-                 device=None):
+                 device=None,
+                 precision="f32"):
         super().__init__()
         if condition not in ("fixed",):
             if condition in ("trainable_spec", "trainable_z"):
@@ -152,6 +153,7 @@ class ClassifierFreeDiffRoll(nn.Module):
         if sa.get("pad_mode", "reflect") != "reflect":
             raise NotImplementedError("only pad_mode='reflect' is supported (config/spec/mel.yaml)")
         self._device = device
+        self.precision = precision          # 'f32' (exact, default) | 'bf16x3' (opt-in split precision)
         self._engine: Optional[Engine] = None
         self._dirty = True
         self._fe_key = None
@@ -169,6 +171,8 @@ class ClassifierFreeDiffRoll(nn.Module):
             self._engine.load_params({k: v for k, v in self.state_dict().items()})
             self._dirty = False
             self._fe_key = None
+        if self._engine.precision != self.precision:
+            self._engine.set_precision(self.precision)
         return self._engine
 
     # schedule vectors, exposed like the reference's attributes (task/diffusion.py:239-256)

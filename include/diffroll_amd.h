@@ -73,6 +73,15 @@ enum {
     DR_COEF_FAMILIES = 5
 };
 
+/* arithmetic of the two hot contractions (dilated conv, 1x1 output projection); everything else is fp32 */
+enum {
+    DR_PRECISION_F32 = 0,     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the default                     */
+    DR_PRECISION_BF16X3 = 1   /* opt-in: each fp32 operand is split EXACTLY into three bf16 pieces and a
+                                 product is formed from the six piece products with i + j <= 2 on the bf16
+                                 MFMA with fp32 accumulation (drops terms <= 2^-24 |ab|); fp32-level error
+                                 at 2.67x the matrix rate                                                  */
+};
+
 /* which spectrogram a dr_forward evaluation sees (model/diffwave.py:656-660) */
 enum {
     DR_COND_SPEC = 0,    /* the spectrogram of the last dr_frontend call   */
@@ -176,6 +185,10 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  */
 int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, size_t n, float threshold,
                     int64_t* host_counts, void* stream);
+
+/* Select DR_PRECISION_* for subsequent dr_forward / dr_step / dr_sample calls (default F32).
+ * Drops a captured chain. */
+int dr_set_precision(dr_engine* e, int mode);
 
 /* Timing of the dominant kernel (dilated conv + gate) inside dr_sample, measured with HIP events
  * on the launch stream when enabled: returns launches and total milliseconds since last reset. */

@@ -32,7 +32,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inpainting_f=None):
+def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inpainting_f=None, precision="f32"):
     from diffroll_amd import ClassifierFreeDiffRoll
     m = ClassifierFreeDiffRoll(
         residual_channels=hp["residual_channels"], unconditional=False, condition="fixed",
@@ -44,7 +44,7 @@ def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inp
                        normalized=True, pad_mode="reflect"),
         spec_dropout=0.1, inpainting_t=inpainting_t, inpainting_f=inpainting_f,
         timesteps=hp["timesteps"], beta_start=hp["beta_start"], beta_end=hp["beta_end"],
-        training={"mode": "x_0"}, sampling={"type": sampler, "w": w})
+        training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, precision=precision)
     m.load_state_dict(params)
     return m
 
@@ -290,3 +290,64 @@ def test_frame_f1_matches_sklearn(full_model):
     wav = 0.1 * torch.randn(2, 64000)
     out = m2.test_step({"frame": label[:2], "audio": wav}, 0)
     assert 0.0 <= out["Test/Frame_F1"] <= 1.0 and out["tp"] + out["fn"] == int(label[:2].sum())
+
+
+# --------------------------------------------------------------------------------------------
+# opt-in split-bf16 precision (DR_PRECISION_BF16X3): held to the SAME tolerances as the exact-fp32 path
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["forward_k3", "forward_k9", "forward_k15", "forward_wide_k9"])
+def test_bf16x3_forward_golden(golden_dir, name):
+    g = load(golden_dir, name)
+    hp, p, m = fixture_model(g, precision="bf16x3")
+    x, wav = T(g["x"]), T(g["wav"])
+    t = torch.tensor(int(g["t"])).repeat(x.shape[0])
+    x0_c, _ = m(x, wav, t)
+    x0_u, _ = m(x, torch.zeros_like(wav), t, sampling=True)
+    assert m.engine.precision == "bf16x3"
+    assert maxdiff(x0_c.cpu(), g["x0_c"]) <= ATOL_FWD, maxdiff(x0_c.cpu(), g["x0_c"])
+    assert maxdiff(x0_u.cpu(), g["x0_u"]) <= ATOL_FWD, maxdiff(x0_u.cpu(), g["x0_u"])
+
+
+@pytest.mark.parametrize("sampler", ["cfdg_ddpm_x0", "generation_ddpm_x0"])
+def test_bf16x3_chain_golden(golden_dir, sampler):
+    g = load(golden_dir, "steps_chain_k9")
+    hp, p, m = fixture_model(g, sampler=sampler, w=float(g["w"]), precision="bf16x3")
+    x, wav, noise = T(g["x"]), T(g["wav"]), T(g["noise"])
+    for use_graph in (False, True):
+        roll, _ = m.sample(x, wav, noise=noise, use_graph=use_graph)
+        d = maxdiff(roll.cpu(), g[f"{sampler}_chain"])
+        assert d <= ATOL_STEP, (use_graph, d)
+
+
+def test_bf16x3_full_size_forward_and_config1_chain_vs_oracle():
+    hp = dict(R.DEFAULT_HP)
+    p = R.synthetic_params(hp, seed=0)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, precision="bf16x3")
+    torch.manual_seed(0)
+    B, L = 2, 64000
+    Tn = L // 512
+    wav = 0.1 * torch.randn(B, L)
+    x = torch.randn(B, 1, Tn, 88)
+    t = torch.tensor(117).repeat(B)
+    with torch.no_grad():
+        ref_c, _ = R.forward(p, hp, x, wav, t)
+        ref_u, _ = R.forward(p, hp, x, torch.zeros_like(wav), t, sampling=True)
+    x0_c, _ = m(x, wav, t)
+    x0_u, _ = m(x, wav, t, sampling=True)
+    dc, du = maxdiff(x0_c.cpu(), ref_c), maxdiff(x0_u.cpu(), ref_u)
+    assert dc <= ATOL_FWD and du <= ATOL_FWD, (dc, du)
+    # exact-fp32 engine on the same inputs: the two precisions agree far inside the tolerance
+    m32 = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    y32, _ = m32(x, wav, t)
+    assert maxdiff(x0_c.cpu(), y32.cpu()) <= ATOL_FWD
+    # config 1 chain (50 steps)
+    hp1 = dict(hp)
+    hp1["timesteps"] = 50
+    m1 = make_model(hp1, p, sampler="cfdg_ddpm_x0", w=0.5, precision="bf16x3")
+    wav1, x1 = wav[:1], x[:1]
+    noise = torch.randn(50, 1, 1, Tn, 88)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp1, "cfdg_ddpm_x0", x1, wav1, noise, w=0.5)
+    roll, _ = m1.sample(x1, wav1, noise=noise)
+    d = maxdiff(roll.cpu(), ref)
+    assert d <= ATOL_STEP, d

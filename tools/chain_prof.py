@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import bench
 dev = torch.device("cuda", 0)
 m = bench.build_model(dev)
+m.precision = sys.argv[1] if len(sys.argv) > 1 else "f32"
 T = bench.L_SAMPLES // 512
 wav = (0.1 * torch.randn(bench.B_LOCAL, bench.L_SAMPLES)).to(dev)
 x = torch.randn(bench.B_LOCAL, 1, T, 88).to(dev)

@@ -22,11 +22,13 @@ def main():
     ap.add_argument("--layers", default="0,1,2,3")
     ap.add_argument("--uncond", action="store_true", help="all samples unconditional (generation)")
     ap.add_argument("--pointwise", action="store_true", help="time the 1x1 output projection kernel instead")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
     args = ap.parse_args()
     hp = dict(bench.HP)
     hp["kernel_size"] = args.k
     dev = torch.device("cuda", 0)
     m = bench.build_model(dev, hp=hp)
+    m.precision = args.precision
     eng = m.engine
     L = args.T * hp["hop_length"]
     wav = (0.1 * torch.randn(args.B, L)).to(dev)
