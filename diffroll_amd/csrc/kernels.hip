@@ -24,7 +24,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DR_DEVINL __device__ __forceinline__
 
 // DR_ABLATE (compile-time, measurement builds only; results are WRONG when non-zero):
-//   1 = no A-fragment prefetch in the K loop, 9 = producers do no loads / LDS writes (barriers only)
+//   1 = no A-fragment prefetch in the K loop, 2 = (S3 path) A fragments always from slab 0 (cache-hot),
+//   9 = producers do no loads / LDS writes (barriers only)
 #ifndef DR_ABLATE
 #define DR_ABLATE 0
 #endif
@@ -268,8 +269,14 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         // one K step (32 channels x 1 tap): 2 groups x 6 piece products x 2 x NI tiles = 24*NI MFMAs per wave
         auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
             constexpr bool kB = decltype(ROLE)::value;
+#if DR_ABLATE == 2          // measurement build: always the same slab (L1-hot A loads)
+            if constexpr (kB) wA = load_a3(0); else wB = load_a3(0);
+#elif DR_ABLATE == 1        // measurement build: no A loads at all
+            if constexpr (kB) wA = wB; else wB = wA;
+#else
             if constexpr (kB) wA = load_a3(min(slab + 1, NS - 1));
             else wB = load_a3(min(slab + 1, NS - 1));
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const uint4* Xb = Xs3 + ((chunk & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WN + r;
             uint4 bf[2][3][NI];
