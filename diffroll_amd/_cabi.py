@@ -31,7 +31,7 @@ PRECISIONS = {"f32": 0, "bf16x3": 1}
 # every symbol include/diffroll_amd.h declares
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
-    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_frame_counts", "dr_set_precision", "dr_profile_enable",
+    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
 ]
 
@@ -85,6 +85,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_sample.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, vp]
     lib.dr_frame_counts.restype = C.c_int
     lib.dr_frame_counts.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_int64), vp]
+    lib.dr_note_runs.restype = C.c_int
+    lib.dr_note_runs.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
     lib.dr_set_precision.restype = C.c_int
     lib.dr_set_precision.argtypes = [vp, C.c_int]
     lib.dr_profile_enable.restype = C.c_int

@@ -841,6 +841,14 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     return DR_OK;
 }
 
+int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end, void* stream) {
+    if (!e || !d_roll || !d_note_end) return fail(e, DR_EINVAL, "null argument");
+    if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
+    HIPCHK(e, hipSetDevice(e->cfg.device));
+    HIPCHK(e, launch_note_runs(d_roll, d_note_end, B, T, threshold, (hipStream_t)stream));
+    return DR_OK;
+}
+
 int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, size_t n, float threshold,
                     int64_t* host_counts, void* stream) {
     if (!e || !d_pred || !d_label || !host_counts) return fail(e, DR_EINVAL, "null argument");

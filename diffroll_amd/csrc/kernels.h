@@ -102,6 +102,10 @@ hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4,
                             int B, int planes_in, int planes_out, int TF, int T, int n_rows,
                             int mt0, int mt1, int mf0, int mf1, hipStream_t s);
 hipError_t launch_fill(float* p, float v, long n, hipStream_t s);
+// note_end[b][t][p] = offset frame (exclusive) of the note that STARTS at frame t on pitch p, else 0:
+// roll (B, T, 88) thresholded at thr; a note = maximal run of frames above the threshold (rule1 with
+// onsets == frames, task/diffusion.py:1185-1233)
+hipError_t launch_note_runs(const float* roll, int* note_end, int B, int T, float thr, hipStream_t s);
 // counts[0..2] += {TP, FP, FN} of (pred > thr) against (label > 0.5) over n elements (exact integers)
 hipError_t launch_frame_counts(const float* pred, const float* label, float thr, long n,
                                unsigned long long* counts, hipStream_t s);

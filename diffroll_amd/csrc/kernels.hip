@@ -863,6 +863,29 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Roll -> note runs (task/diffusion.py:1185-1233 with onsets == frames, rule1): one thread per
+// (sample, pitch) column walks the T frames once, backwards, so every note start learns its offset in
+// O(T) total; lanes of a wave cover 64 consecutive pitches of a frame (coalesced 256-B reads).  Index
+// work: results are exact integers.
+__global__ __launch_bounds__(128) void note_runs_kernel(const float* __restrict__ roll, int* __restrict__ note_end,
+                                                        int T, float thr) {
+    const int b = blockIdx.x, p = threadIdx.x;
+    if (p >= 88) return;
+    const float* col = roll + (long)b * T * 88 + p;
+    int* out = note_end + (long)b * T * 88 + p;
+    int end = 0;          // offset (exclusive) of the run containing frame t, 0 when frame t is off
+    for (int t = T - 1; t >= 0; --t) {
+        const bool on = col[(long)t * 88] > thr;
+        if (on) { if (end == 0) end = t + 1; } else end = 0;
+        const bool prev_on = (t > 0) && (col[(long)(t - 1) * 88] > thr);
+        out[(long)t * 88] = (on && !prev_on) ? end : 0;
+    }
+}
+hipError_t launch_note_runs(const float* roll, int* note_end, int B, int T, float thr, hipStream_t s) {
+    hipLaunchKernelGGL(note_runs_kernel, dim3((unsigned)B), dim3(128), 0, s, roll, note_end, T, thr);
+    return hipGetLastError();
+}
+
 // Frame-level confusion counts of task/diffusion.py:381-383 (sklearn precision_recall_fscore_support,
 // average='binary', on label.flatten() vs pred.flatten() > threshold): HBM-bound, 8 B per element,
 // integer-exact (per-lane counters -> wave shuffles -> one 64-bit atomic per wave), so the metric does

@@ -176,6 +176,17 @@ class Engine:
                                                  self._stream()))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def note_runs(self, roll: torch.Tensor, threshold: float) -> torch.Tensor:
+        """roll (B, T, 88) -> int32 (B, T, 88): at each note start the (exclusive) end frame, else 0."""
+        r = self._dev(roll)
+        B, T, K = r.shape
+        assert K == 88
+        out = torch.empty(B, T, 88, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_note_runs(self.h, r.data_ptr(), B, T, float(threshold), out.data_ptr(),
+                                              self._stream()))
+        return out
+
     def set_precision(self, mode: str):
         """'f32' (default, exact fp32 MFMA) or 'bf16x3' (opt-in split-bf16: three bf16 pieces per operand,
         six piece products, fp32 accumulation - fp32-level error at 2.67x the matrix rate)."""

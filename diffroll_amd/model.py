@@ -375,6 +375,15 @@ class ClassifierFreeDiffRoll(nn.Module):
         p, r, f = self.frame_metrics(tp, fp, fn)
         return {"Test/Frame_F1": f, "Test/Frame_precision": p, "Test/Frame_recall": r, "tp": tp, "fp": fp, "fn": fn}
 
+    def export_midi(self, roll, path_prefix="raw_midi_", threshold=0.5):
+        """Post-processing of predict_step (task/diffusion.py:598-618): threshold the final roll (the
+        reference uses the function default 0.5 there, not hparams.frame_threshold), extract notes on the
+        GPU, drop notes shorter than hparams.generation_filter seconds and write one MIDI file per sample."""
+        from . import midi
+        sa = self.hparams.spec_args
+        return midi.export_midi(self.engine, roll, path_prefix, threshold, int(sa.get("hop_length", 512)),
+                                int(sa.get("sample_rate", 16000)), float(self.hparams.generation_filter))
+
     def sampling(self, batch, batch_idx=0):
         """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""
         frame = batch["frame"]

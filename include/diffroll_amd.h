@@ -178,6 +178,15 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
               float w, uint64_t seed, int first_sample, int use_graph, void* stream);
 
 /*
+ * Roll -> notes, the scan of extract_notes_wo_velocity (task/diffusion.py:1185-1233) as the reference's
+ * drivers call it (onsets == frames == the roll, one threshold, rule1): d_note_end (B, T, 88) int32
+ * receives, at every (frame, pitch) where a note STARTS, the frame index at which it ends (exclusive),
+ * and 0 elsewhere.  np.nonzero() of that tensor enumerates the notes in the reference's order.
+ */
+int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end,
+                 void* stream);
+
+/*
  * Frame-level evaluation of test_step (task/diffusion.py:381-383): confusion counts of
  * (d_pred > threshold) against the binary label roll over n elements, the integers sklearn's
  * precision_recall_fscore_support(average='binary') is computed from.  host_counts = {TP, FP, FN}.

@@ -400,3 +400,32 @@ def synthetic_params(hp: dict, seed: int = 0) -> Dict[str, Tensor]:
     p["output_projection.weight"] = torch.randn(88, C, 1, generator=g) * 0.02
     p["output_projection.bias"] = unif((88,), C)
     return p
+
+
+# --------------------------------------------------------------------------
+# post-processing: roll -> notes  (task/diffusion.py:1185-1233)
+# --------------------------------------------------------------------------
+def extract_notes_wo_velocity(onsets, frames, onset_threshold=0.5, frame_threshold=0.5, rule="rule1"):
+    """numpy restatement of task/diffusion.py:1185-1233: a note starts at a rising edge of the thresholded
+    onset roll (rule1: where the frame roll is on too) and lasts while either roll stays on.
+    onsets, frames: (T, 88) arrays -> (pitches (N,), intervals (N, 2) [onset, offset))."""
+    import numpy as np
+    onsets = (np.asarray(onsets) > onset_threshold).astype(int)
+    frames = (np.asarray(frames) > frame_threshold).astype(int)
+    onset_diff = np.concatenate([onsets[:1, :], onsets[1:, :] - onsets[:-1, :]], axis=0) == 1
+    if rule == "rule1":
+        onset_diff = onset_diff & (frames == 1)
+    elif rule != "rule2":
+        raise NameError("Please enter the correct rule name")
+    pitches, intervals = [], []
+    frame_locs, pitch_locs = np.nonzero(onset_diff)
+    for frame, pitch in zip(frame_locs, pitch_locs):
+        onset = offset = frame
+        while onsets[offset, pitch] or frames[offset, pitch]:
+            offset += 1
+            if offset == onsets.shape[0]:
+                break
+        if offset > onset:
+            pitches.append(pitch)
+            intervals.append([onset, offset])
+    return np.array(pitches), np.array(intervals)

@@ -175,14 +175,40 @@ def gen_extra_samplers():
     save("steps_chain_extra_k9", **arrays)
 
 
+def gen_notes():
+    """the reference's own extract_notes_wo_velocity (task/diffusion.py:1185) on seeded rolls."""
+    RI.import_reference_model()
+    import task.diffusion as TD          # the reference's module
+    rng = np.random.default_rng(7)
+    rolls, out = [], {}
+    for i, (Tn, density) in enumerate([(125, 0.03), (640, 0.01), (40, 0.3), (16, 0.0), (16, 1.0)]):
+        # smooth-ish random roll: blocks of activity so that runs of several frames exist
+        base = rng.random((Tn // 4 + 1, 88)) < density * 3
+        roll = np.repeat(base, 4, axis=0)[:Tn].astype(np.float32) * rng.uniform(0.55, 1.2, (Tn, 88)).astype(np.float32)
+        roll += rng.uniform(0, 0.45, (Tn, 88)).astype(np.float32) * (rng.random((Tn, 88)) < 0.5)
+        if density == 1.0:
+            roll[:] = 0.9
+        rolls.append(roll)
+        for thr in (0.5, 0.8):
+            p_, i_ = TD.extract_notes_wo_velocity(roll, roll, onset_threshold=thr, frame_threshold=thr, rule="rule1")
+            out[f"roll{i}"] = roll
+            out[f"pitches{i}_{thr}"] = np.asarray(p_, dtype=np.int64)
+            out[f"intervals{i}_{thr}"] = np.asarray(i_, dtype=np.int64).reshape(-1, 2)
+    save("notes", n=len(rolls), **out)
+
+
 if __name__ == "__main__":
     assert RI.reference_available(), "needs /root/reference"
     torch.set_num_threads(8)
     if "--extra-only" in sys.argv:
         gen_extra_samplers()
         sys.exit(0)
+    if "--notes-only" in sys.argv:
+        gen_notes()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
     gen_steps_and_chain()
     gen_extra_samplers()
+    gen_notes()

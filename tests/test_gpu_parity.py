@@ -351,3 +351,28 @@ def test_bf16x3_full_size_forward_and_config1_chain_vs_oracle():
     roll, _ = m1.sample(x1, wav1, noise=noise)
     d = maxdiff(roll.cpu(), ref)
     assert d <= ATOL_STEP, d
+
+
+def test_note_extraction_bit_exact_and_midi(golden_dir, full_model, tmp_path):
+    """GPU note scan == the reference's extract_notes_wo_velocity (integer work: bit exact),
+    then MIDI export round trip."""
+    from diffroll_amd import midi
+    hp, p, m = full_model
+    g = load(golden_dir, "notes")
+    eng = m.engine
+    for i in range(int(g["n"])):
+        roll = T(g[f"roll{i}"])[None]
+        for thr in (0.5, 0.8):
+            (pitches, intervals), = midi.extract_notes_wo_velocity(eng, roll, thr)
+            assert np.array_equal(pitches, g[f"pitches{i}_{thr}"]), (i, thr)
+            assert np.array_equal(intervals, g[f"intervals{i}_{thr}"]), (i, thr)
+            op, oi = R.extract_notes_wo_velocity(g[f"roll{i}"], g[f"roll{i}"], thr, thr)
+            assert np.array_equal(pitches, np.asarray(op, dtype=np.int64))
+    # batched call + export
+    rolls = torch.stack([T(g["roll0"]), T(g["roll0"]).flip(1)])[:, None]
+    paths = midi.export_midi(eng, rolls, str(tmp_path / "raw_midi_"), threshold=0.5)
+    assert len(paths) == 2
+    ev = midi.read_midi_notes(paths[0])
+    n_notes = len(g["pitches0_0.5"])
+    assert len(ev) == 2 * n_notes and sum(1 for e in ev if e[1] == 0x90) == n_notes
+    assert all(midi.MIN_MIDI <= e[2] <= 108 for e in ev) and all(b[0] >= a[0] for a, b in zip(ev, ev[1:]))

@@ -149,3 +149,19 @@ def test_shard_bounds_partition():
                 assert 0 <= lo <= hi <= n and hi - lo in (n // ws, n // ws + 1)
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def test_midi_writer_round_trip(tmp_path):
+    from diffroll_amd import midi
+    runs = np.zeros((10, 88), dtype=np.int32)
+    runs[0, 3] = 4      # note on pitch 3 frames [0, 4)
+    runs[2, 40] = 3     # [2, 3)
+    runs[5, 3] = 10     # [5, 10)
+    pitches, intervals = midi.notes_from_runs(runs)
+    assert pitches.tolist() == [3, 40, 3] and intervals.tolist() == [[0, 4], [2, 3], [5, 10]]
+    path = str(tmp_path / "t.mid")
+    midi.save_midi(path, (midi.MIN_MIDI + pitches).tolist(), (intervals * 0.032).tolist(), [127] * 3)
+    ev = midi.read_midi_notes(path)
+    assert [e[0] for e in ev] == sorted(e[0] for e in ev) and len(ev) == 6
+    assert ev[0] == (0, 0x90, midi.MIN_MIDI + 3, 127)
+    assert (int(0.128 * 960), 0x80, midi.MIN_MIDI + 3, 127) in ev

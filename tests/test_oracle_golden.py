@@ -110,3 +110,13 @@ def test_extra_samplers_steps_and_chain(golden_dir, sampler):
             assert np.allclose(out.numpy(), g[f"{sampler}_t{t_index}"], atol=ATOL), t_index
         final = R.sample_chain(p, hp, sampler, x, wav, noise, w)
     assert np.allclose(final.numpy(), g[f"{sampler}_chain"], atol=ATOL)
+
+
+def test_note_extraction_matches_reference(golden_dir):
+    """integer/index work - bit exact against the reference's own function."""
+    g = load(golden_dir, "notes")
+    for i in range(int(g["n"])):
+        for thr in (0.5, 0.8):
+            p_, i_ = R.extract_notes_wo_velocity(g[f"roll{i}"], g[f"roll{i}"], thr, thr)
+            assert np.array_equal(np.asarray(p_, dtype=np.int64), g[f"pitches{i}_{thr}"])
+            assert np.array_equal(np.asarray(i_, dtype=np.int64).reshape(-1, 2), g[f"intervals{i}_{thr}"])
