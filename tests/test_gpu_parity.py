@@ -376,3 +376,53 @@ def test_note_extraction_bit_exact_and_midi(golden_dir, full_model, tmp_path):
     n_notes = len(g["pitches0_0.5"])
     assert len(ev) == 2 * n_notes and sum(1 for e in ev if e[1] == 0x90) == n_notes
     assert all(midi.MIN_MIDI <= e[2] <= 108 for e in ev) and all(b[0] >= a[0] for a, b in zip(ev, ev[1:]))
+
+
+# --------------------------------------------------------------------------------------------
+# edge cases: ragged frame counts (T = 1, below the halo, around the 64/128-frame tile sizes), B = 1,
+# all kernel sizes, every dilation, both precisions - one evaluation + one guided step vs the oracle
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [3, 9, 15])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_ragged_shapes_vs_oracle(k, precision):
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=4, kernel_size=k, timesteps=6)   # dilations 1,2,4,8
+    p = R.synthetic_params(hp, seed=900 + k)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.7, precision=precision)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    g = torch.Generator().manual_seed(k)
+    for B, Tn in ((1, 1), (2, 7), (1, 63), (3, 64), (1, 65), (2, 129), (1, 200)):
+        L = max(Tn * 512, 2048)                      # reflect padding needs L > n_fft / 2
+        wav = 0.1 * torch.randn(B, L, generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        z = torch.randn(B, 1, Tn, 88, generator=g)
+        t = torch.tensor(3).repeat(B)
+        with torch.no_grad():
+            ref, ref_spec = R.forward(p, hp, x, wav, t)
+            spec_c = R.frontend(wav, hp, Tn)
+            ref_step = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, spec_c, 3, z, 0.7)
+        out, spec = m(x, wav, t)
+        assert out.shape == ref.shape and spec.shape == ref_spec.shape
+        d = maxdiff(out.cpu(), ref)
+        assert d <= ATOL_FWD, (B, Tn, d)
+        assert maxdiff(spec.cpu(), ref_spec) <= ATOL_SPEC
+        step, _ = m.reverse_diffusion(x, wav, 3, noise=z)
+        d = maxdiff(step.cpu(), ref_step)
+        assert d <= ATOL_STEP, (B, Tn, d)
+
+
+def test_roll_longer_than_spectrogram_is_trimmed(full_model):
+    """trim_spec_roll (model/diffwave.py:30-39): T_roll > L // hop + 1 -> outputs have T' = L // hop + 1 frames."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=2, kernel_size=3, timesteps=4)
+    p = R.synthetic_params(hp, seed=5)
+    m = make_model(hp, p, sampler="ddpm_x0")
+    torch.manual_seed(0)
+    wav = 0.1 * torch.randn(2, 10 * 512)          # spectrogram has 11 frames
+    x = torch.randn(2, 1, 20, 88)
+    t = torch.tensor(1).repeat(2)
+    with torch.no_grad():
+        ref, ref_spec = R.forward(p, hp, x, wav, t)
+    out, spec = m(x, wav, t)
+    assert out.shape == ref.shape == (2, 1, 11, 88) and spec.shape == ref_spec.shape
+    assert maxdiff(out.cpu(), ref) <= ATOL_FWD
