@@ -165,3 +165,26 @@ def test_midi_writer_round_trip(tmp_path):
     assert [e[0] for e in ev] == sorted(e[0] for e in ev) and len(ev) == 6
     assert ev[0] == (0, 0x90, midi.MIN_MIDI + 3, 127)
     assert (int(0.128 * 960), 0x80, midi.MIN_MIDI + 3, 127) in ev
+
+
+def test_cli_config_overrides(tmp_path):
+    from diffroll_amd import cli
+    cfg = cli.build_config(["task=inpainting", "task.inpainting_t=[10,20]", "model.args.kernel_size=9",
+                            "dataset=Custom", "dataset.args.audio_path=/x", "dataloader.batch_size=16", "gpus=8",
+                            "task.sampling.w=1.5", "checkpoint_path=null"])
+    assert cfg["task"]["sampling"] == {"type": "inpainting_ddpm_x0", "w": 1.5}
+    assert cfg["task"]["inpainting_t"] == [10, 20] and cfg["model"]["args"]["kernel_size"] == 9
+    assert cfg["dataset"]["args"]["audio_path"] == "/x" and cfg["dataloader"]["batch_size"] == 16
+    assert cfg["checkpoint_path"] is None and cfg["gpus"] == 8
+    assert cli.build_config([])["task"]["sampling"]["type"] == "generation_ddpm_x0"
+    with pytest.raises(SystemExit):
+        cli.build_config(["task=nope"])
+    # wav ingestion: stereo int16 @ 8 kHz -> mono float, resampled to 16 kHz, zero padded (custom_dataset.py:55-91)
+    from scipy.io import wavfile
+    sr = 8000
+    tt = np.arange(sr) / sr
+    stereo = np.stack([np.sin(2 * np.pi * 440 * tt), np.zeros_like(tt)], 1)
+    wavfile.write(str(tmp_path / "a.wav"), sr, (stereo * 20000).astype(np.int16))
+    w = cli.load_wav_folder(dict(audio_path=str(tmp_path), audio_ext="wav", max_segment_samples=20000, sample_rate=16000))
+    assert w.shape == (1, 20000) and float(w[0, 16000:].abs().max()) == 0.0
+    assert 0.25 < float(w[0, :16000].abs().max()) < 0.35      # mean of (0.61 sine, 0) channels
