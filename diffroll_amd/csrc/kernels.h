@@ -75,7 +75,7 @@ struct GemmArgs {
 hipError_t init_kernels();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
-size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec);
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 int gemm_max_halo(int NI);
 
 struct UpdateArgs {

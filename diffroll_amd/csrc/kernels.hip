@@ -14,6 +14,7 @@
 // Written for wave64 / 4 waves per workgroup; no other target is supported.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace dr {
@@ -128,8 +129,19 @@ template <int NI, int KS, int EPI, int PREC>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 64 * NI;
-    constexpr int WN = 32 * NI;
     constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
+    // Consumer wave arrangement.  Paired epilogues (gate / |.|^2) need the two row tiles of a channel in
+    // one wave: 2 (M) x 2 (N), wave tile 64 rows x 32*NI frames.  All other GEMMs use 4 (M) x 1 (N), wave
+    // tile 32 rows x 64*NI frames: every wave then loads DISTINCT A fragments (in 2 x 2 the two N-waves
+    // load identical ones, and for the K = 512 1x1 GEMM those duplicate 32 KB per K step pushed the block
+    // to ~16 B/clk of L2->CU traffic, above what a CU's vector memory path sustains: measured 89 vs 67
+    // ticks per MFMA); the X tile is shared through LDS either way.
+    constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_POWER);
+    constexpr int WNC = PAIRED ? 2 : 1;           // consumer waves along N
+    constexpr int MI = PAIRED ? 2 : 1;            // 32-row MFMA tiles per wave
+    constexpr int NW = PAIRED ? NI : 2 * NI;      // 32-frame MFMA tiles per wave
+    constexpr int WROWS = MI * 32;                // rows per wave
+    constexpr int WFR = NW * 32;                  // frames per wave
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,6 +151,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     const int halo = ((a.taps - 1) >> 1) * a.dil;
     const int FW = BN + 2 * halo;
     float4* Xs = reinterpret_cast<float4*>(smem);   // [2][XP][FW]
+    // EPI_RES_SKIP: the tile of h (residual rows) / skip (skip rows) this block read-modify-writes,
+    // [32 planes][BN frames] float4, DMA'd by the producers at kernel start and read by the epilogue.
+    // (Holding it in 64 prefetch VGPRs instead cost the compiler the B-fragment software pipelining.)
+    float4* Rs = Xs + 2 * XP * FW;
 
     // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
     // one 128-row weight panel, which then stays resident in that XCD's private L2.
@@ -196,6 +212,20 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
             }
         };
+        if constexpr (EPI == EPI_RES_SKIP) {
+            const unsigned rrecs = (unsigned)a.T * 16u;
+            constexpr int RWL = BN / 64;
+            for (int i = pw; i < 32 * RWL; i += 4) {
+                const int pl = i / RWL, seg = i - pl * RWL;
+                const int row0 = mt * 128 + pl * 4;
+                const float* src = (row0 < a.y_rows)
+                    ? a.Y + (long)b * a.y_bs + (long)(row0 >> 2) * a.y_ps
+                    : a.skip + (long)b * a.s_bs + (long)((row0 - a.y_rows) >> 2) * a.T * 4;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rrecs, 0x00020000);
+                const int voff = (t0 + seg * 64 + lane) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, voff, 0, 0, 0);
+            }
+        }
 #if DR_ABLATE != 9
         issue(0);
 #endif
@@ -212,43 +242,23 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 
     // ---------------------------------------------------------------------- consumers
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WNC, wc = wave % WNC;
     const int r = lane & 31, hi = lane >> 5;
     // this lane's A fragments inside a slab: fp32 [g][hi][row][4] (16 KiB); S3 [g16][piece][kq][row][8 bf16] (24 KiB)
-    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * (PREC ? 1536 : 1024) + hi * 128 + wr * 64 + r;
+    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * (PREC ? 1536 : 1024) + hi * 128 + wr * WROWS + r;
 
-    f32x16 acc[2][NI];
+    f32x16 acc[MI][NW];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NW; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
-    // EPI_RES_SKIP read-modify-writes h (residual rows) or skip (skip rows): those operands come from
-    // HBM, so they are loaded NOW (branch-free) and their latency hides behind the K loop.  Everything
-    // else the epilogues need (bias, d2, conditioner) is L2-resident and is loaded as unconditional
-    // batches at the start of the epilogue: a conditional load there compiles to a branch +
-    // s_waitcnt vmcnt(0) per quad (a chain of serialized round trips), while prefetching all of it here
-    // pushed the kernel over the 256-VGPR budget of a 512-thread block and into scratch.
-    constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_POWER);
-    float4 eop[2][NI][4];
-    if constexpr (EPI == EPI_RES_SKIP) {
-        const bool is_res = (mt * 128 + wr * 64) < a.y_rows;     // wave-uniform row class
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int t = min(t0 + wc * WN + ni * 32 + r, a.T - 1);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p0 = mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi;
-                    const float* src = is_res ? a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs
-                                              : a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
-                    eop[mi][ni][q] = *reinterpret_cast<const float4*>(src);
-                }
-        }
-    }
+    // Epilogue operands are NOT prefetched into VGPRs: bias / d2 / conditioner are L2-resident and are
+    // loaded as unconditional batches at the start of the epilogue (a conditional load there compiles to
+    // a branch + s_waitcnt vmcnt(0) per quad), the EPI_RES_SKIP read-modify-write tile waits in LDS (Rs).
+    float4 eop[MI][NW][4];
 
     if constexpr (PREC == 1) {
         const uint4* Wg3 = reinterpret_cast<const uint4*>(Wg);
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int pz = 0; pz < 3; ++pz)
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) o.v[(g * 3 + pz) * 2 + mi] = src[(g * 3 + pz) * 256 + mi * 32];
+                    for (int mi = 0; mi < MI; ++mi) o.v[(g * 3 + pz) * 2 + mi] = src[(g * 3 + pz) * 256 + mi * 32];
             return o;
         };
         A12 wA = load_a3(0), wB;
@@ -278,24 +288,24 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             else wB = load_a3(min(slab + 1, NS - 1));
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const uint4* Xb = Xs3 + ((chunk & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WN + r;
-            uint4 bf[2][3][NI];
+            const uint4* Xb = Xs3 + ((chunk & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+            uint4 bf[2][3][NW];
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bf[0][pz][ni] = Xb[(pz * 2) * FW + ni * 32];
+                for (int ni = 0; ni < NW; ++ni) bf[0][pz][ni] = Xb[(pz * 2) * FW + ni * 32];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 if (g == 0) {
 #pragma unroll
                     for (int pz = 0; pz < 3; ++pz)
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) bf[1][pz][ni] = Xb[(6 + pz * 2) * FW + ni * 32];
+                        for (int ni = 0; ni < NW; ++ni) bf[1][pz][ni] = Xb[(6 + pz * 2) * FW + ni * 32];
                 }
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
+                    for (int ni = 0; ni < NW; ++ni) {
                         const uint4 a0 = kB ? wB.v[(g * 3 + 0) * 2 + mi] : wA.v[(g * 3 + 0) * 2 + mi];
                         const uint4 a1 = kB ? wB.v[(g * 3 + 1) * 2 + mi] : wA.v[(g * 3 + 1) * 2 + mi];
                         const uint4 a2 = kB ? wB.v[(g * 3 + 2) * 2 + mi] : wA.v[(g * 3 + 2) * 2 + mi];
@@ -308,6 +318,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                         acc[mi][ni] = mma_bf16(a0, bf[g][0][ni], acc[mi][ni]);
                     }
             }
+            // pin the software pipeline (see the fp32 path): both groups' fragment reads first
+            sgb<0x100, 3 * NW>();
+            sgb<0x100, 3 * NW>(); sgb<0x8, 6 * MI * NW>();
+            sgb<0x8, 6 * MI * NW>();
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) o.v[g * 2 + mi] = src[g * 256 + mi * 32];
+            for (int mi = 0; mi < MI; ++mi) o.v[g * 2 + mi] = src[g * 256 + mi * 32];
         return o;
     };
 
@@ -359,21 +373,21 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         // MFMA stream with sched_group_barrier was measured slower (317 vs 300 us per launch).
         __builtin_amdgcn_sched_barrier(0);
 
-        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WN + r;
-        float4 bf[2][NI];
+        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+        float4 bf[2][NW];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = Xb[ni * 32];
+        for (int ni = 0; ni < NW; ++ni) bf[0][ni] = Xb[ni * 32];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             if (g < 3) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bf[nxt][ni] = Xb[(g + 1) * 2 * FW + ni * 32];
+                for (int ni = 0; ni < NW; ++ni) bf[nxt][ni] = Xb[(g + 1) * 2 * FW + ni * 32];
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
+                for (int ni = 0; ni < NW; ++ni) {
                     const float4 af = kB ? wB.v[g * 2 + mi] : wA.v[g * 2 + mi];
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[cur][ni].x, acc[mi][ni], 0, 0, 0);
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[cur][ni].y, acc[mi][ni], 0, 0, 0);
@@ -381,6 +395,13 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[cur][ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
+        // Pin the software pipeline: group g+1's fragment reads are issued BEFORE group g's MFMAs (hipcc
+        // otherwise sinks them below the MFMAs and waits at once, exposing the LDS latency 4x per step).
+        sgb<0x100, NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
+        sgb<0x8, 4 * MI * NW>();
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -417,40 +438,47 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
     // ----------------------------------------------------------------------------------------
     auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
-    float4 ebias[2][4];                         // [mi][q]
-    float4 ed2[2][4];                           // second-output offset (step embedding of the next conv)
+    float4 ebias[MI][4];                        // [mi][q]
+    float4 ed2[MI][4];                          // second-output offset (step embedding of the next conv)
     {
         const float* bsrc = a.bias;
         if constexpr (EPI == EPI_GATE) bsrc = (b < a.n_cond) ? a.bias : a.bias2;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                ebias[mi][q] = *reinterpret_cast<const float4*>(bsrc + mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi);
+                ebias[mi][q] = *reinterpret_cast<const float4*>(bsrc + mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi);
         if constexpr (EPI == EPI_RELU || EPI == EPI_RES_SKIP) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     // residual rows only exist below y_rows; the clamp keeps the (unused) skip-row loads in range
-                    const int p0 = min(mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
+                    const int p0 = min(mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
                     ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + p0);
                 }
         }
     }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int t = t0 + wc * WN + ni * 32 + r;
+    for (int ni = 0; ni < NW; ++ni) {
+        const int t = t0 + wc * WFR + ni * 32 + r;
+        if constexpr (EPI == EPI_RES_SKIP) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    eop[mi][ni][q] = Rs[(wr * (WROWS / 4) + mi * 8 + 2 * q + hi) * BN + wc * WFR + ni * 32 + r];
+        }
         if constexpr (EPI == EPI_GATE) {
             // conditioner quads of this frame column: one unconditional batch (unconditional samples read
             // sample 0's tensor - valid memory - and ignore it)
             const int tc = min(t, a.T - 1);
             const float* cb = a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs + (long)tc * 4;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int p0 = mt * 128 + wr * 64 + mi * 32 + 8 * q + 4 * hi;
+                    const int p0 = mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi;
                     eop[mi][ni][q] = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
                 }
         }
@@ -489,8 +517,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 }
             } else {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int p0 = mt * 128 + wr * 64 + mi * 32 + rq;
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int p0 = mt * 128 + wr * WROWS + mi * 32 + rq;
                     float v[4], bb[4], o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
@@ -557,10 +585,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec) {
+size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
     const int halo = ((taps - 1) / 2) * dil;
     const int FW = 64 * NI + 2 * halo;
-    return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16;
+    return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * 64 * NI * 16 : 0);
 }
 int gemm_max_halo(int NI) { return (256 - 64 * NI) / 2; }
 
@@ -568,7 +596,7 @@ template <int NI, int KS, int EPI, int PREC>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 64 * NI;
     const int tps = (a.T + BN - 1) / BN;
-    const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil, PREC);
+    const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil, PREC, EPI);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * tps;
     const dim3 grid((unsigned)(a.MT * NT));
@@ -576,6 +604,8 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
     const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
+    if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
     hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
 }
@@ -636,8 +666,12 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int pr
             return a.kchunks % 4 == 0 ? launch_gemm_t<1, 4, EPI_RES_SKIP, 1>(a, s) : launch_gemm_t<1, 1, EPI_RES_SKIP, 1>(a, s);
         return hipErrorInvalidValue;
     }
-    // 1x1 GEMMs restage X every step: take up to 128 channels per chunk there (fewer hand-overs)
-    const int KS = a.taps != 1 ? 1 : (a.kchunks % 4 == 0 ? 4 : (a.kchunks % 2 == 0 ? 2 : 1));
+    // 1x1 GEMMs restage X every step: take up to 128 channels per chunk there (fewer hand-overs);
+    // EPI_RES_SKIP also keeps its read-modify-write tile in LDS, which leaves room for 64 channels at NI = 2
+    int KS = a.taps != 1 ? 1 : (a.kchunks % 4 == 0 ? 4 : (a.kchunks % 2 == 0 ? 2 : 1));
+    if (epi == EPI_RES_SKIP && NI == 2 && KS == 4) KS = 2;
+    static const int ks_force = getenv("DR_1X1_KS") ? atoi(getenv("DR_1X1_KS")) : 0;   // tuning experiments
+    if (ks_force && a.taps == 1 && a.kchunks % ks_force == 0) KS = ks_force;
     if (NI == 1) {
         if (KS == 4) return launch_gemm_ni<1, 4>(a, epi, s);
         return KS == 2 ? launch_gemm_ni<1, 2>(a, epi, s) : launch_gemm_ni<1, 1>(a, epi, s);
