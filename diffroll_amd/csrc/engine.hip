@@ -244,15 +244,45 @@ size_t expected_numel(const dr_engine* e, const std::string& name) {
 // Frame-tile size (NI = 1: 64 frames, 2: 128 frames per block) for a GEMM of MT row tiles over NB samples
 // of T frames: minimise (block rounds over the 256 CUs) x (tile cost); 128-frame tiles win ties (half the
 // weight traffic per MFMA).  One block per CU is resident (LDS / 512-thread blocks).
-int pick_ni(int MT, int NB, int T, int taps, int dil) {
+// Frame-tile choice for a GEMM of MT row tiles over NB samples of T frames.  flavor 0: gemm_kernel
+// (32x32 MFMA) with NI = n (64*n frames per block); flavor 1: gemm16_kernel (16x16 MFMA) with NJ = n
+// (32*n frames per block, fp32 hot kernels only).  Cost = (block rounds over the 256 CUs, one block per
+// CU) x (frames per block); 16x16 tiles carry a small penalty (more operand reads per MFMA), 128-frame
+// 32x32 tiles win ties.
+struct Tile { int flavor, n; };
+Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool allow16) {
+    static const char* forced = getenv("DR_TILE");     // tuning experiments: "32:2", "16:5", ... (if it fits)
     const int halo = ((taps - 1) / 2) * dil;
-    static const int forced = getenv("DR_CONV_NI") ? atoi(getenv("DR_CONV_NI")) : 0;   // tuning experiments
-    const bool fits2 = 128 + 2 * halo <= 256;
-    if (forced == 1 || (forced == 2 && fits2)) return forced;
-    if (!fits2) return 1;
-    const long b2 = (long)MT * NB * ((T + 127) / 128), b1 = (long)MT * NB * ((T + 63) / 64);
-    const long c2 = ((b2 + 255) / 256) * 2, c1 = (b1 + 255) / 256;
-    return c1 < c2 ? 1 : 2;
+    struct Cand { int flavor, n, bn; double pen; };
+    const Cand cands[] = {{0, 2, 128, 1.0}, {1, 5, 160, 1.04}, {1, 6, 192, 1.04}, {1, 3, 96, 1.04}, {0, 1, 64, 1.0}};
+    auto feasible = [&](const Cand& c) {
+        if (c.flavor == 1 && (!allow16 || prec != 0)) return false;
+        const int ks = (taps == 1) ? 2 : 1;
+        const size_t lds = (c.flavor == 0)
+            ? gemm_lds_bytes(c.n, (taps == 1 && c.n == 1) ? 4 : ks, taps, dil, prec, epi)
+            : (size_t)2 * 8 * ks * (c.bn + 2 * halo) * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * c.bn * 16 : 0);
+        return lds <= 160 * 1024;
+    };
+    if (forced && strlen(forced) >= 4) {
+        const int ff = forced[0] == '1' ? 1 : 0, fn = atoi(forced + 3);
+        for (const Cand& c : cands)
+            if (c.flavor == ff && c.n == fn && feasible(c)) return Tile{ff, fn};
+    }
+    Tile best{0, 1};
+    double best_cost = 1e30;
+    for (const Cand& c : cands) {
+        if (!feasible(c)) continue;
+        const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
+        const double cost = (double)((blocks + 255) / 256) * c.bn * c.pen;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = Tile{c.flavor, c.n}; }
+    }
+    return best;
+}
+int pick_ni(int MT, int NB, int T, int taps, int dil, int prec = 0) {
+    return pick_tile(MT, NB, T, taps, dil, prec, EPI_GATE, false).n;
+}
+hipError_t launch_tiled(const GemmArgs& a, int epi, Tile t, hipStream_t s, int prec) {
+    return t.flavor == 1 ? launch_gemm16(a, epi, t.n, s) : launch_gemm(a, epi, t.n, s, prec);
 }
 
 // common GemmArgs for a P4 activation input [NB][planes][T][4]
@@ -332,7 +362,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if (prec) { a.Y = e->g3; a.y_bs = s3_bs; a.out_s3 = 1; }
             const bool timed = e->prof && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-            HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), st, prec));
+            HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true), st, prec));
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
         }
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
@@ -345,7 +375,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 else { a.Y2 = e->hd; a.y2_bs = act_bs; }
             }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
-            HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, prec ? 1 : pick_ni(Cp / 64, NB, T, 1, 1), st, prec));
+            HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), st, prec));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
@@ -463,9 +493,10 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
         for (int q = 0; q < i % cfg->dilation_bound; ++q) d *= cfg->dilation_base;
         maxdil = std::max(maxdil, d);
     }
-    if (64 + (e->K - 1) * maxdil > 256) {
+    if (gemm_lds_bytes(1, 1, e->K, maxdil, 1, EPI_GATE) > 160 * 1024) {
+        const int rf = (e->K - 1) * maxdil;
         delete e;
-        return fail(nullptr, DR_EINVAL, "receptive halo (k-1)*dil = %d too large for the LDS tile", (e->K - 1) * maxdil);
+        return fail(nullptr, DR_EINVAL, "receptive halo (k-1)*dil = %d does not fit the 160 KiB LDS tile", rf);
     }
     *out = e;
     return DR_OK;
@@ -928,7 +959,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    HIPCHK(e, launch_gemm(a, EPI_GATE, pick_ni(Cp / 64, NB, T, e->K, w.dil), (hipStream_t)stream, e->prec));
+    HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, e->prec, EPI_GATE, true), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
 
@@ -955,7 +986,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
-    HIPCHK(e, launch_gemm(a, EPI_RES_SKIP, e->prec ? 1 : pick_ni(Cp / 64, NB, T, 1, 1), (hipStream_t)stream, e->prec));
+    HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, e->prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
 

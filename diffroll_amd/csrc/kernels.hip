@@ -585,12 +585,301 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flexible-width variant on v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue): 16-frame column tiles,
+// so a block covers BN = 32*NJ frames for any NJ (96, 160, 192 ...).  Used when 64/128-frame tiles
+// quantise badly over the 256 CUs (config 5: 8 x 640 frames -> 4 x 160-frame tiles per clip = exactly
+// 256 blocks instead of 2.5 rounds of 64-frame blocks).  Same packed weights (the slab is
+// [channel/4][row][4], which serves both MFMA shapes), same LDS-DMA producers, same P4 layouts.
+//   paired epilogue (EPI_GATE): consumers 2 (M) x 2 (N), wave tile = 4 row tiles (gate 16+16, filter
+//   16+16 of the same 32 channels) x NJ column tiles; otherwise (EPI_RES_SKIP) 4 (M) x 1 (N), wave tile
+//   = 2 row tiles x 2*NJ column tiles.  20 accumulators x 4 registers at NJ = 5.
+// ---------------------------------------------------------------------------------------------
+template <int NJ, int KS, int EPI>
+__global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(EPI == EPI_GATE || EPI == EPI_RES_SKIP, "16x16 variant: hot kernels only");
+    constexpr int BN = 32 * NJ;
+    constexpr int XP = 8 * KS;
+    constexpr bool PAIRED = (EPI == EPI_GATE);
+    constexpr int WNC = PAIRED ? 2 : 1;
+    constexpr int RT = PAIRED ? 4 : 2;              // 16-row tiles per wave
+    constexpr int CT = PAIRED ? NJ : 2 * NJ;        // 16-frame tiles per wave
+    constexpr int WROWS = RT * 16, WFR = CT * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int halo = ((a.taps - 1) >> 1) * a.dil;
+    const int FW = BN + 2 * halo;
+    float4* Xs = reinterpret_cast<float4*>(smem);   // [2][XP][FW]
+    float4* Rs = Xs + 2 * XP * FW;                  // EPI_RES_SKIP: [32 planes][BN]
+
+    int mt, nt;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        nt = (idx / a.MT) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        nt = blockIdx.x / a.MT;
+    }
+    const int tps = (a.T + BN - 1) / BN;
+    const int b = nt / tps;
+    const int t0 = (nt % tps) * BN;
+    const int NS = a.kchunks * a.taps;
+    const int nchunks = a.kchunks / KS;
+
+    if (wave >= 4) {   // producers: identical to gemm_kernel's (LDS-DMA, hardware zero padding)
+        const int pw = wave - 4;
+        const int bx = a.x_bmod ? (b % a.x_bmod) : b;
+        const float* Xg = a.X + (long)bx * a.x_bs;
+        const int last_plane = a.x_planes - 1;
+        const unsigned recs = ((unsigned)(a.T - 1) * (unsigned)a.x_fs + 4u) * 4u;
+        const int wl = (FW + 63) >> 6;
+        const int total = XP * wl;
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        auto issue = [&](int chunk) {
+            for (int i = pw; i < total; i += 4) {
+                const int pl = i / wl, seg = i - pl * wl;
+                const int f = seg * 64 + lane;
+                const float* src = Xg + (long)min(chunk * XP + pl, last_plane) * a.x_ps;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
+                const int voff = (t0 - halo + f) * (int)a.x_fs * 4;
+                float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
+                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
+            }
+        };
+        if constexpr (EPI == EPI_RES_SKIP) {
+            const unsigned rrecs = (unsigned)a.T * 16u;
+            constexpr int RWL = (BN + 63) / 64;
+            for (int i = pw; i < 32 * RWL; i += 4) {
+                const int pl = i / RWL, seg = i - pl * RWL;
+                const int row0 = mt * 128 + pl * 4;
+                const float* src = (row0 < a.y_rows)
+                    ? a.Y + (long)b * a.y_bs + (long)(row0 >> 2) * a.y_ps
+                    : a.skip + (long)b * a.s_bs + (long)((row0 - a.y_rows) >> 2) * a.T * 4;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rrecs, 0x00020000);
+                const int f = seg * 64 + lane;
+                if (f < BN)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0 + f) * 16, 0, 0, 0);
+            }
+        }
+        issue(0);
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            __syncthreads();
+            if (chunk + 1 < nchunks) issue(chunk + 1);
+        }
+        return;
+    }
+
+    // consumers.  16x16x4: A lane (i = l&15, kq = l>>4) holds W[row i][4 channels kq*4..+3 of a 16-channel
+    // group] (one per MFMA), B lane (j = l&15, kq) the matching X values; C/D: column = l&15,
+    // rows (l>>4)*4 + reg -> one float4 of the P4 layout per tile.
+    const int wr = wave / WNC, wc = wave % WNC;
+    const int li = lane & 15, kq = lane >> 4;
+    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024 + kq * 128 + wr * WROWS + li;
+
+    float4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f4zero();
+
+    struct AF { float4 v[2 * RT]; };   // [g16][rt]
+    auto load_a = [&](int slab) -> AF {
+        AF o;
+        const float4* src = Wg + (long)slab * 1024;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) o.v[g * RT + rt] = src[g * 512 + rt * 16];
+        return o;
+    };
+    AF wA = load_a(0), wB;
+    const int cen = (a.taps - 1) >> 1;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+
+    auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
+        constexpr bool kB = decltype(ROLE)::value;
+        if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
+        else wB = load_a(min(slab + 1, NS - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + kq) * FW + halo + (j - cen) * a.dil + wc * WFR + li;
+        float4 bf[2][CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bf[0][ct] = Xb[ct * 16];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bf[1][ct] = Xb[4 * FW + ct * 16];
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float4 af = kB ? wB.v[g * RT + rt] : wA.v[g * RT + rt];
+                    v4f c = {acc[rt][ct].x, acc[rt][ct].y, acc[rt][ct].z, acc[rt][ct].w};
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[g][ct].x, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[g][ct].y, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[g][ct].z, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[g][ct].w, c, 0, 0, 0);
+                    acc[rt][ct] = make_float4(c[0], c[1], c[2], c[3]);
+                }
+        }
+        sgb<0x100, CT>();
+        sgb<0x100, CT>(); sgb<0x8, 4 * RT * CT>();
+        sgb<0x8, 4 * RT * CT>();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    const int per_chunk = a.taps * KS;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        auto at = [&](auto R, int q) {
+            const int j = q / KS, sub = q - j * KS;
+            step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+        };
+        __syncthreads();
+        int q = 0;
+        for (; q + 2 <= per_chunk; q += 2) {
+            at(F_{}, q);
+            at(T_{}, q + 1);
+        }
+        if (q < per_chunk) {
+            at(F_{}, q);
+            wA = wB;
+        }
+    }
+
+    // epilogue: per (row tile, column tile) a lane owns rows rowbase + kq*4 .. +3 of frame column li
+    auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
+    const int rowb = mt * 128 + wr * WROWS + kq * 4;     // + rt*16
+    float4 ebias[RT], ed2[RT];
+    {
+        const float* bsrc = a.bias;
+        if constexpr (EPI == EPI_GATE) bsrc = (b < a.n_cond) ? a.bias : a.bias2;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            ebias[rt] = *reinterpret_cast<const float4*>(bsrc + rowb + rt * 16);
+            if constexpr (EPI == EPI_RES_SKIP)
+                ed2[rt] = *reinterpret_cast<const float4*>(a.d2 + min(rowb + rt * 16, a.y_rows - 4));
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int t = t0 + wc * WFR + ct * 16 + li;
+        if constexpr (EPI == EPI_GATE) {
+            float4 cnd[RT];
+            const int tc = min(t, a.T - 1);
+            const float* cb = a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs + (long)tc * 4;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) cnd[rt] = *reinterpret_cast<const float4*>(cb + (long)((rowb + rt * 16) >> 2) * a.T * 4);
+            if (t >= a.T) continue;
+            const bool has_c = b < a.n_cond;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {     // gate tiles rt, filter tiles rt + 2
+                const int c0 = mt * 64 + wr * 32 + rt * 16 + kq * 4;
+                if (c0 >= a.y_rows) continue;
+                float v0[4], v1[4], b0[4], b1[4], c0v[4], c1v[4], o[4];
+                f4arr(acc[rt][ct], v0); f4arr(acc[rt + 2][ct], v1);
+                f4arr(ebias[rt], b0); f4arr(ebias[rt + 2], b1);
+                f4arr(cnd[rt], c0v); f4arr(cnd[rt + 2], c1v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
+                    const float a1 = has_c ? b1[e] + c1v[e] : b1[e];
+                    o[e] = sigmoidf_(v0[e] + a0) * tanhf(v1[e] + a1);
+                }
+                if (a.out_s3 & 1) {
+                    store_s3_quad(a.Y + (long)b * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
+                } else {
+                    float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        } else {
+            float4 pv4[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                pv4[rt] = Rs[((wr * WROWS + rt * 16) / 4 + kq) * BN + wc * WFR + ct * 16 + li];
+            if (t >= a.T) continue;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int p0 = rowb + rt * 16;
+                float v[4], bb[4], pv[4], o[4];
+                f4arr(acc[rt][ct], v); f4arr(ebias[rt], bb); f4arr(pv4[rt], pv);
+                if (p0 < a.y_rows) {
+                    float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (a.Y2) {
+                        float dd[4];
+                        f4arr(ed2[rt], dd);
+                        const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                        if (a.out_s3 & 2) {
+                            store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                        } else {
+                            float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                            *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                        }
+                    }
+                } else {
+                    float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
+                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int NJ, int KS, int EPI>
+static hipError_t launch_gemm16_t(const GemmArgs& a, hipStream_t s) {
+    const int BN = 32 * NJ;
+    const int halo = ((a.taps - 1) / 2) * a.dil;
+    const size_t lds = (size_t)2 * 8 * KS * (BN + 2 * halo) * 16 + (EPI == EPI_RES_SKIP ? (size_t)32 * BN * 16 : 0);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int NT = a.NB * ((a.T + BN - 1) / BN);
+    GemmArgs b = a;
+    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    hipLaunchKernelGGL((gemm16_kernel<NJ, KS, EPI>), dim3((unsigned)(a.MT * NT)), dim3(512), lds, s, b);
+    return hipGetLastError();
+}
+// frames per block = 32 * NJ; NJ in {3, 5, 6}: 96 / 160 / 192 (64 and 128 are served by gemm_kernel)
+hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s) {
+    if (a.kchunks < 1) return hipErrorInvalidValue;
+    if (epi == EPI_GATE) {
+        if (NJ == 3) return launch_gemm16_t<3, 1, EPI_GATE>(a, s);
+        if (NJ == 5) return launch_gemm16_t<5, 1, EPI_GATE>(a, s);
+        if (NJ == 6) return launch_gemm16_t<6, 1, EPI_GATE>(a, s);
+    } else if (epi == EPI_RES_SKIP && a.taps == 1 && a.kchunks % 2 == 0) {
+        if (NJ == 3) return launch_gemm16_t<3, 2, EPI_RES_SKIP>(a, s);
+        if (NJ == 5) return launch_gemm16_t<5, 2, EPI_RES_SKIP>(a, s);
+        if (NJ == 6) return launch_gemm16_t<6, 2, EPI_RES_SKIP>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+static hipError_t init_gemm16() {
+    hipError_t e;
+#define DR_INIT16(NJ, KS, EPI)                                                                           \
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NJ, KS, EPI>),            \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) \
+        return e;
+    DR_INIT16(3, 1, EPI_GATE) DR_INIT16(5, 1, EPI_GATE) DR_INIT16(6, 1, EPI_GATE)
+    DR_INIT16(3, 2, EPI_RES_SKIP) DR_INIT16(5, 2, EPI_RES_SKIP) DR_INIT16(6, 2, EPI_RES_SKIP)
+#undef DR_INIT16
+    return hipSuccess;
+}
+
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
     const int halo = ((taps - 1) / 2) * dil;
     const int FW = 64 * NI + 2 * halo;
     return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * 64 * NI * 16 : 0);
 }
-int gemm_max_halo(int NI) { return (256 - 64 * NI) / 2; }
 
 template <int NI, int KS, int EPI, int PREC>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
@@ -640,7 +929,8 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
-    return init_gemm_t<1, 1, EPI_RES_SKIP, 1>();
+    if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
+    return init_gemm16();
 }
 
 template <int NI, int KS>
@@ -658,8 +948,7 @@ static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec) {
-    const int halo = ((a.taps - 1) / 2) * a.dil;
-    if (64 * NI + 2 * halo > 256 || a.kchunks < 1) return hipErrorInvalidValue;
+    if (a.kchunks < 1) return hipErrorInvalidValue;   // the X tile width is only bounded by LDS (checked per launch)
     if (prec == 1) {   // split-bf16 input: only the two hot kernels exist in this precision
         if (epi == EPI_GATE) return NI == 1 ? launch_gemm_t<1, 1, EPI_GATE, 1>(a, s) : launch_gemm_t<2, 1, EPI_GATE, 1>(a, s);
         if (epi == EPI_RES_SKIP && a.taps == 1)

@@ -426,3 +426,37 @@ def test_roll_longer_than_spectrogram_is_trimmed(full_model):
     out, spec = m(x, wav, t)
     assert out.shape == ref.shape == (2, 1, 11, 88) and spec.shape == ref_spec.shape
     assert maxdiff(out.cpu(), ref) <= ATOL_FWD
+
+
+def test_flexible_width_tiles_vs_oracle(monkeypatch):
+    """The 16x16-MFMA flexible-width kernels (96 / 160 / 192-frame blocks) are chosen by shape; force each
+    one and hold it to the oracle on a shape that exercises ragged tails and every dilation."""
+    import subprocess, sys, textwrap
+    # the tile override is read once per process: run each forced variant in a child process
+    code = textwrap.dedent("""
+        import sys, torch, numpy as np
+        sys.path.insert(0, %r)
+        from oracle import diffroll_ref as R
+        from tests.test_gpu_parity import make_model
+        hp = dict(R.DEFAULT_HP); hp.update(residual_channels=128, residual_layers=4, kernel_size=9, timesteps=6)
+        p = R.synthetic_params(hp, seed=77)
+        m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], 6)
+        g = torch.Generator().manual_seed(5)
+        worst = 0.0
+        for B, Tn in ((2, 200), (1, 333), (3, 97)):
+            wav = 0.1 * torch.randn(B, Tn * 512, generator=g); x = torch.randn(B, 1, Tn, 88, generator=g)
+            z = torch.randn(B, 1, Tn, 88, generator=g); t = torch.tensor(2).repeat(B)
+            with torch.no_grad():
+                ref, _ = R.forward(p, hp, x, wav, t)
+                ref_step = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, R.frontend(wav, hp, Tn), 2, z, 0.5)
+            out, _ = m(x, wav, t); step, _ = m.reverse_diffusion(x, wav, 2, noise=z)
+            worst = max(worst, float((out.cpu() - ref).abs().max()), float((step.cpu() - ref_step).abs().max()))
+        print("WORST", worst)
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for tile in ("16:3", "16:5", "16:6", "32:2", "32:1"):
+        env = dict(os.environ, DR_TILE=tile)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tile, r.stderr[-2000:])
+        worst = float(r.stdout.strip().split("WORST")[-1])
+        assert worst <= ATOL_FWD, (tile, worst)
