@@ -34,7 +34,7 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
 def gather_rolls(local: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather equally sized local rolls (b, 1, T, 88) into (world*b, 1, T, 88), rank-major."""
     d = _dist()
-    if d is None or d.get_world_size(group) == 1:
+    if d is None:
         return local
     ws = d.get_world_size(group)
     local = local.contiguous()
