@@ -1,17 +1,22 @@
 // gfx950 (MI355X, CDNA4) kernels of the DiffRoll sampling engine.
 //
-// One templated implicit-GEMM kernel on the exact-fp32 matrix instruction
-// v_mfma_f32_32x32x2_f32 carries every contraction of the path:
+// One implicit-GEMM design carries every contraction of the path, in three consumer flavours that share
+// the LDS-DMA producers, the P4 / S3 activation layouts and the packed weights:
+//   gemm_kernel<.., PREC=0>  exact fp32 on v_mfma_f32_32x32x2_f32      (default; 64/128-frame blocks)
+//   gemm_kernel<.., PREC=1>  split-bf16 on v_mfma_f32_32x32x16_bf16    (opt-in "bf16x3", hot kernels)
+//   gemm16_kernel            exact fp32 on v_mfma_f32_16x16x4_f32      (96/160/192-frame blocks, hot kernels)
+// used for
 //   * dilated Conv1d (k taps) + conditioner add + sigmoid*tanh gate   (model/diffwave.py:139-147)
-//   * 1x1 output projection + residual/skip update                     (model/diffwave.py:149-151)
+//   * 1x1 output projection + residual/skip update (+ h + d_next)      (model/diffwave.py:149-151, :138)
 //   * input / skip / output projections of the net                     (model/diffwave.py:667-668, 683-685)
 //   * conditioner projections, step-embedding MLP                      (hoisted; :126,128,65-74)
 //   * the STFT as a windowed-DFT GEMM and the mel filterbank GEMM      (torchaudio MelSpectrogram)
-// plus small HBM-bound kernels: posterior update + classifier-free combine + Philox noise
-// (task/diffusion.py:953-967), reflect padding, per-sample min/max + normalise/mask/trim
-// (model/utils.py:21-32, model/diffwave.py:644-662).
+// plus small HBM-bound kernels: posterior update (all nine samplers) + classifier-free combine + Philox
+// noise (task/diffusion.py:804-1055), reflect padding, per-sample min/max + normalise/mask/trim
+// (model/utils.py:21-32, model/diffwave.py:644-662), frame confusion counts (:381-383) and the
+// roll -> note-run scan (:1185-1233).
 //
-// Written for wave64 / 4 waves per workgroup; no other target is supported.
+// Written for wave64, 512-thread workgroups (4 consumer + 4 producer waves); gfx950 only.
 #include "kernels.h"
 
 #include <cstdlib>
@@ -75,27 +80,12 @@ DR_DEVINL f32x16 mma_bf16(const uint4 a, const uint4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// sched_group_barrier helpers (masks: 0x8 MFMA, 0x20 VMEM read, 0x100 DS read): NV times
-// {GAP MFMAs, 1 VMEM read}, ND times {GAP MFMAs, 1 DS read}, then REM MFMAs.
+// sched_group_barrier helper (masks: 0x8 MFMA, 0x100 DS read): the next N instructions of that class
+// are scheduled here, in program order - used to pin the fragment-read software pipeline.
 template <int MASK, int N>
 DR_DEVINL void sgb() {
     if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
 }
-template <int GAP, int NV, int ND, int REM>
-DR_DEVINL void spread_mem() {
-    if constexpr (NV > 0) {
-        sgb<0x8, GAP>();
-        sgb<0x20, 1>();
-        spread_mem<GAP, NV - 1, ND, REM>();
-    } else if constexpr (ND > 0) {
-        sgb<0x8, GAP>();
-        sgb<0x100, 1>();
-        spread_mem<GAP, 0, ND - 1, REM>();
-    } else {
-        sgb<0x8, REM>();
-    }
-}
-
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -109,8 +99,8 @@ DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 //                (2 MFMA row-tiles: for the paired epilogues the gate/cos tile and the filter/sin tile
 //                of the SAME 32 channels, so pairing is register-local).  They only issue MFMAs, the
 //                A-fragment loads and the B-fragment ds_reads.
-//     waves 4-7  producers: stage the X tile of the NEXT chunk (global -> registers -> + step
-//                embedding, zero padding -> LDS) while the consumers compute the current one.
+//     waves 4-7  producers: stage the X tile of the NEXT chunk with LDS-DMA (hardware zero padding)
+//                while the consumers compute the current one.
 //   One s_barrier per chunk hands a staged buffer over (double buffered).
 //
 //   A operand (weights): NEVER staged through LDS.  The packed layout is fragment-shaped, so every
