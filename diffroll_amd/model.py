@@ -206,12 +206,11 @@ class ClassifierFreeDiffRoll(nn.Module):
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides):
         """Lightning-style: ``{'state_dict', 'hyper_parameters'}``; keyword overrides win
-        (sampling.py:54-65).  Reading a real Lightning .ckpt needs its pickled OmegaConf classes
-        importable; a plain ``torch.save({'state_dict':..., 'hyper_parameters': dict})`` always works."""
-        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
-        hp = dict(ckpt.get("hyper_parameters", {}))
-        hp.update(overrides)
-        m = cls(**hp)
+        (sampling.py:54-65).  OmegaConf containers inside a real reference checkpoint are read without
+        omegaconf / pytorch_lightning installed (diffroll_amd/checkpoint.py)."""
+        from .checkpoint import constructor_kwargs, load_checkpoint
+        ckpt = load_checkpoint(checkpoint_path)
+        m = cls(**constructor_kwargs(cls, ckpt["hyper_parameters"], overrides))
         m.load_state_dict(ckpt["state_dict"], strict=False)
         return m
 

@@ -188,3 +188,62 @@ def test_cli_config_overrides(tmp_path):
     w = cli.load_wav_folder(dict(audio_path=str(tmp_path), audio_ext="wav", max_segment_samples=20000, sample_rate=16000))
     assert w.shape == (1, 20000) and float(w[0, 16000:].abs().max()) == 0.0
     assert 0.25 < float(w[0, :16000].abs().max()) < 0.35      # mean of (0.61 sine, 0) channels
+
+
+def test_checkpoint_with_omegaconf_shaped_hparams_loads_without_omegaconf(tmp_path):
+    """A Lightning-style checkpoint whose hyper_parameters hold objects of classes that cannot be imported at
+    load time (as OmegaConf DictConfig / ListConfig / value nodes are here) still loads: SURVEY 5.4."""
+    import sys, types
+    fake = types.ModuleType("omegaconf_fake_for_test")
+
+    class DictConfig:
+        def __init__(self, content):
+            self._content = {k: wrap(v) for k, v in content.items()}
+            self._metadata = Meta()
+
+    class ListConfig:
+        def __init__(self, content):
+            self._content = [wrap(v) for v in content]
+
+    class AnyNode:
+        def __init__(self, v):
+            self._val = v
+
+    class Meta:
+        def __init__(self):
+            self.key = None
+
+    def wrap(v):
+        if isinstance(v, dict):
+            return DictConfig(v)
+        if isinstance(v, list):
+            return ListConfig(v)
+        return AnyNode(v)
+
+    for cls_ in (DictConfig, ListConfig, AnyNode, Meta):
+        cls_.__module__ = fake.__name__
+        cls_.__qualname__ = cls_.__name__
+        setattr(fake, cls_.__name__, cls_)
+    sys.modules[fake.__name__] = fake
+    m = make(kernel_size=9)
+    hp = dict(residual_channels=32, unconditional=False, condition="fixed", n_mels=229,
+              norm_args=ListConfig([0, 1, "imagewise"]), residual_layers=3, kernel_size=9, dilation_base=2,
+              dilation_bound=4, spec_dropout=0.1, timesteps=8, lr=1e-4, loss_type="l2",
+              spec_args=DictConfig(dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000,
+                                        center=True, normalized=True, pad_mode="reflect")),
+              sampling=DictConfig(dict(type="cfdg_ddpm_x0", w=0)), training=DictConfig(dict(mode="x_0")),
+              some_future_key=DictConfig(dict(a=1)))
+    path = str(tmp_path / "last.ckpt")
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": hp, "epoch": 3}, path)
+    del sys.modules[fake.__name__]                      # the classes are now un-importable, like omegaconf here
+    from diffroll_amd import ClassifierFreeDiffRoll
+    from diffroll_amd.checkpoint import load_checkpoint
+    ck = load_checkpoint(path)
+    assert ck["hyper_parameters"]["spec_args"]["hop_length"] == 512
+    assert ck["hyper_parameters"]["norm_args"] == [0, 1, "imagewise"]
+    m2 = ClassifierFreeDiffRoll.load_from_checkpoint(path, sampling={"type": "cfdg_ddpm_x0", "w": 0.5},
+                                                     frame_threshold=0.8)
+    assert m2.hparams.sampling.w == 0.5 and m2.hparams.frame_threshold == 0.8      # overrides win
+    assert m2.hparams.kernel_size == 9 and m2.hparams.spec_args.n_fft == 2048
+    for k, v in m.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v)
