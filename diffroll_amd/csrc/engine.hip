@@ -169,12 +169,13 @@ std::vector<uint16_t> pack_weights_s3(int MT, int kchunks, int taps, F get) {
     return out;
 }
 
-// paired row map: packed row -> (which half mi, channel c); 128-row tile = 2 wave-rows x {gate32, filter32}
+// paired row map: packed row -> (which half mi, channel c); a 128-row tile = 4 consumer waves x
+// [16 gate (cos) rows, 16 filter (sin) rows] of the same 16 channels (kernels.hip: pairing inside one MFMA tile)
 inline void paired_row(int prow, int& mi, int& c) {
     const int mt = prow >> 7, rr = prow & 127;
-    const int wr = rr >> 6;
-    mi = (rr >> 5) & 1;
-    c = mt * 64 + wr * 32 + (rr & 31);
+    const int w = rr >> 5, r = rr & 31;
+    mi = r >> 4;
+    c = mt * 64 + w * 16 + (r & 15);
 }
 
 int upload(dr_engine* e, const std::vector<float>& v, float** out) {

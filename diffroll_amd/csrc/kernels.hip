@@ -95,16 +95,16 @@ DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 //   SIMD every non-MFMA instruction cluster in the consumer's in-order stream is exposed - X loads,
 //   select/add VALU, ds_write and the barrier cost 6.7 of 74.6 ticks per MFMA - while instructions of
 //   ANOTHER wave on the same SIMD overlap the 64-cycle MFMAs):
-//     waves 0-3  consumers, one per SIMD, 2 (M) x 2 (N): wave tile 64 rows x 32*NI frames
-//                (2 MFMA row-tiles: for the paired epilogues the gate/cos tile and the filter/sin tile
-//                of the SAME 32 channels, so pairing is register-local).  They only issue MFMAs, the
-//                A-fragment loads and the B-fragment ds_reads.
+//     waves 0-3  consumers, one per SIMD, 4 (M) x 1 (N): wave tile 32 rows x 64*NI frames (for the paired
+//                epilogues the 32 rows are 16 gate/cos + 16 filter/sin rows of the SAME channels, so
+//                pairing is register-local).  They only issue MFMAs, the A-fragment loads and the
+//                B-fragment ds_reads.
 //     waves 4-7  producers: stage the X tile of the NEXT chunk with LDS-DMA (hardware zero padding)
 //                while the consumers compute the current one.
 //   One s_barrier per chunk hands a staged buffer over (double buffered).
 //
 //   A operand (weights): NEVER staged through LDS.  The packed layout is fragment-shaped, so every
-//   consumer wave loads the 8 float4 A-fragments of a K step (4 channel groups x 2 row tiles) straight
+//   consumer wave loads the 4 float4 A-fragments of a K step (4 channel groups x its 32 rows) straight
 //   from L2 into VGPRs with two fully coalesced 512-B segments per instruction, one step ahead of use
 //   (measured free).  The 128-row weight panel of an M tile is L2-resident: blockIdx % MT pins a
 //   panel to an XCD.
@@ -120,16 +120,16 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BN = 64 * NI;
     constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
-    // Consumer wave arrangement.  Paired epilogues (gate / |.|^2) need the two row tiles of a channel in
-    // one wave: 2 (M) x 2 (N), wave tile 64 rows x 32*NI frames.  All other GEMMs use 4 (M) x 1 (N), wave
-    // tile 32 rows x 64*NI frames: every wave then loads DISTINCT A fragments (in 2 x 2 the two N-waves
-    // load identical ones, and for the K = 512 1x1 GEMM those duplicate 32 KB per K step pushed the block
-    // to ~16 B/clk of L2->CU traffic, above what a CU's vector memory path sustains: measured 89 vs 67
-    // ticks per MFMA); the X tile is shared through LDS either way.
+    // Consumer wave arrangement: 4 (M) x 1 (N) - every wave owns 32 distinct rows x all 64*NI frames of the
+    // block, so no two waves issue the same A-fragment loads (a CU's vector-memory path is the stressed
+    // resource: with 2 x 2 the two N-waves fetched identical fragments); the X tile is shared through LDS.
+    // Paired epilogues (gate / |.|^2) find both members of a pair inside one 32-row MFMA tile: packed rows
+    // of a wave are [16 gate (cos) channels, 16 filter (sin) channels], i.e. C/D register quads q and q+2
+    // of the same lane.
     constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_POWER);
-    constexpr int WNC = PAIRED ? 2 : 1;           // consumer waves along N
-    constexpr int MI = PAIRED ? 2 : 1;            // 32-row MFMA tiles per wave
-    constexpr int NW = PAIRED ? NI : 2 * NI;      // 32-frame MFMA tiles per wave
+    constexpr int WNC = 1;                        // consumer waves along N
+    constexpr int MI = 1;                         // 32-row MFMA tiles per wave
+    constexpr int NW = 2 * NI;                    // 32-frame MFMA tiles per wave
     constexpr int WROWS = MI * 32;                // rows per wave
     constexpr int WFR = NW * 32;                  // frames per wave
 
@@ -477,17 +477,18 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         for (int q = 0; q < 4; ++q) {
             const int rq = 8 * q + 4 * hi;   // row offset inside a 32-row MFMA tile
             if constexpr (PAIRED) {
-                const int c0 = mt * 64 + wr * 32 + rq;    // output channel of the quad
+                if (q >= 2) continue;                     // quads 0,1 = gate / cos rows, quads 2,3 = their partners
+                const int c0 = mt * 64 + wr * 16 + rq;    // output channel of the quad (rq = 8q + 4hi < 16)
                 if (c0 >= a.y_rows) continue;
                 float v0[4], v1[4], o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[1][ni][4 * q + e]; }
+                for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[0][ni][4 * (q + 2) + e]; }
                 if constexpr (EPI == EPI_GATE) {
                     // y = conv + b_conv + (Wc spec + bc)   [model/diffwave.py:143-144]; unconditional samples
                     // carry the constant conditioner inside bias2
                     float b0[4], b1[4], c0v[4], c1v[4];
-                    f4arr(ebias[0][q], b0); f4arr(ebias[1][q], b1);
-                    f4arr(eop[0][ni][q], c0v); f4arr(eop[1][ni][q], c1v);
+                    f4arr(ebias[0][q], b0); f4arr(ebias[0][q + 2], b1);
+                    f4arr(eop[0][ni][q], c0v); f4arr(eop[0][ni][q + 2], c1v);
                     const bool has_c = b < a.n_cond;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -581,9 +582,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 // quantise badly over the 256 CUs (config 5: 8 x 640 frames -> 4 x 160-frame tiles per clip = exactly
 // 256 blocks instead of 2.5 rounds of 64-frame blocks).  Same packed weights (the slab is
 // [channel/4][row][4], which serves both MFMA shapes), same LDS-DMA producers, same P4 layouts.
-//   paired epilogue (EPI_GATE): consumers 2 (M) x 2 (N), wave tile = 4 row tiles (gate 16+16, filter
-//   16+16 of the same 32 channels) x NJ column tiles; otherwise (EPI_RES_SKIP) 4 (M) x 1 (N), wave tile
-//   = 2 row tiles x 2*NJ column tiles.  20 accumulators x 4 registers at NJ = 5.
+//   consumers 4 (M) x 1 (N): wave tile = 2 row tiles (paired epilogue: gate 16 / filter 16 of the same
+//   channels) x 2*NJ column tiles = 20 accumulators x 4 registers at NJ = 5.
 // ---------------------------------------------------------------------------------------------
 template <int NJ, int KS, int EPI>
 __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
@@ -591,10 +591,9 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
     static_assert(EPI == EPI_GATE || EPI == EPI_RES_SKIP, "16x16 variant: hot kernels only");
     constexpr int BN = 32 * NJ;
     constexpr int XP = 8 * KS;
-    constexpr bool PAIRED = (EPI == EPI_GATE);
-    constexpr int WNC = PAIRED ? 2 : 1;
-    constexpr int RT = PAIRED ? 4 : 2;              // 16-row tiles per wave
-    constexpr int CT = PAIRED ? NJ : 2 * NJ;        // 16-frame tiles per wave
+    constexpr int WNC = 1;                          // 4 (M) x 1 (N) consumers, as in gemm_kernel
+    constexpr int RT = 2;                           // 16-row tiles per wave (paired: tile 0 gate, tile 1 filter)
+    constexpr int CT = 2 * NJ;                      // 16-frame tiles per wave
     constexpr int WROWS = RT * 16, WFR = CT * 16;
 
     const int tid = threadIdx.x;
@@ -767,14 +766,13 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
             for (int rt = 0; rt < RT; ++rt) cnd[rt] = *reinterpret_cast<const float4*>(cb + (long)((rowb + rt * 16) >> 2) * a.T * 4);
             if (t >= a.T) continue;
             const bool has_c = b < a.n_cond;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {     // gate tiles rt, filter tiles rt + 2
-                const int c0 = mt * 64 + wr * 32 + rt * 16 + kq * 4;
+            {                                    // tile 0 = gate rows, tile 1 = filter rows of the same 16 channels
+                const int c0 = mt * 64 + wr * 16 + kq * 4;
                 if (c0 >= a.y_rows) continue;
                 float v0[4], v1[4], b0[4], b1[4], c0v[4], c1v[4], o[4];
-                f4arr(acc[rt][ct], v0); f4arr(acc[rt + 2][ct], v1);
-                f4arr(ebias[rt], b0); f4arr(ebias[rt + 2], b1);
-                f4arr(cnd[rt], c0v); f4arr(cnd[rt + 2], c1v);
+                f4arr(acc[0][ct], v0); f4arr(acc[1][ct], v1);
+                f4arr(ebias[0], b0); f4arr(ebias[1], b1);
+                f4arr(cnd[0], c0v); f4arr(cnd[1], c1v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
