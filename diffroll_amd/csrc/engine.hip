@@ -67,6 +67,10 @@ struct dr_engine {
 
     // activation workspace (sized for ws_NB samples x ws_T frames)
     int ws_NB = 0, ws_T = 0;
+    // split-K workspace (partials) and ticket counters, see gemm_kernel
+    float* sk_ws = nullptr;
+    float* sk_cnt = nullptr;
+    static constexpr size_t SK_WS_FLOATS = (size_t)8 << 20, SK_CNT_N = 4096;
     float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
     float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
     int prec = 0;                          // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3, 6 products)
@@ -285,6 +289,11 @@ int pick_ni(int MT, int NB, int T, int taps, int dil, int prec = 0) {
 hipError_t launch_tiled(const GemmArgs& a, int epi, Tile t, hipStream_t s, int prec) {
     return t.flavor == 1 ? launch_gemm16(a, epi, t.n, s) : launch_gemm(a, epi, t.n, s, prec);
 }
+// let the launcher split K when the launch under-fills the chip (single clips, narrow projections)
+void allow_splitk(const dr_engine* e, GemmArgs& a) {
+    a.ws = e->sk_ws; a.ws_cnt = reinterpret_cast<unsigned*>(e->sk_cnt);
+    a.ws_floats = dr_engine::SK_WS_FLOATS; a.ws_cnt_n = dr_engine::SK_CNT_N;
+}
 
 // common GemmArgs for a P4 activation input [NB][planes][T][4]
 const float* g_zero_vec = nullptr;   // device zero vector shared by every engine of the process
@@ -347,6 +356,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.d2 = e->d_dtab + (size_t)t * L * Cp;
         if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
         else { a.Y2 = e->hd; a.y2_bs = act_bs; }
+        allow_splitk(e, a);
         HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
     }
     for (int l = 0; l < L; ++l) {
@@ -361,6 +371,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             a.n_cond = n_cond;
             p4_out(a, e->g, P, T, Cp);
             if (prec) { a.Y = e->g3; a.y_bs = s3_bs; a.out_s3 = 1; }
+            allow_splitk(e, a);
             const bool timed = e->prof && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
             HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true), st, prec));
@@ -376,6 +387,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 else { a.Y2 = e->hd; a.y2_bs = act_bs; }
             }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
+            allow_splitk(e, a);
             HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), st, prec));
         }
     }
@@ -383,11 +395,13 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         GemmArgs a = p4_gemm(e->skip_w, e->skip_b, (Cp + 127) / 128, e->skip, P, NB, T);
         a.alpha = (float)(1.0 / std::sqrt((double)L));
         p4_out(a, e->tmp, P, T, Cp);
+        allow_splitk(e, a);
         HIPCHK(e, launch_gemm(a, EPI_RELU, 1, st));   // M = C only: 64-frame tiles to fill more CUs
     }
     {   // output projection, written straight into the (B,T,88) roll layout (:685-686)
         GemmArgs a = p4_gemm(e->outp_w, e->outp_b, 1, e->tmp, P, NB, T);
         a.Y = x0_out; a.y_bs = (long)T * 88; a.y_ps = 4; a.y_fs = 88; a.y_rows = 88;
+        allow_splitk(e, a);
         HIPCHK(e, launch_gemm(a, EPI_PLAIN, 1, st));  // M = 88 (one row tile): 64-frame tiles
     }
     return DR_OK;
@@ -515,7 +529,7 @@ void dr_destroy(dr_engine* e) {
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
-                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm};
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -696,6 +710,8 @@ int dr_commit(dr_engine* e, void* stream) {
     if ((rc = dev_alloc(e, &e->d_coef, (size_t)DR_COEF_FAMILIES * S * 5))) return rc;
     HIPCHK(e, hipMemcpy(e->d_coef, e->h_coef.data(), (size_t)DR_COEF_FAMILIES * S * 5 * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = dev_alloc(e, &e->d_dtab, (size_t)S * L * Cp))) return rc;
+    if ((rc = dev_alloc(e, &e->sk_ws, dr_engine::SK_WS_FLOATS, false))) return rc;
+    if ((rc = dev_alloc(e, &e->sk_cnt, dr_engine::SK_CNT_N))) return rc;
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by
         // the same GEMM kernel; result d_dtab[t][l][c].
@@ -960,6 +976,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
+    allow_splitk(e, a);
     HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, e->prec, EPI_GATE, true), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
@@ -987,6 +1004,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
         e->dbg_ticks = (long long*)q;
     }
     a.dbg = e->dbg_ticks;
+    allow_splitk(e, a);
     HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, e->prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), (hipStream_t)stream, e->prec));
     return DR_OK;
 }

@@ -68,6 +68,12 @@ struct GemmArgs {
     int skip_init;           // 1: skip = value, 0: skip += value
     float alpha;
     int xcd_n;               // set by the launcher: block -> (M tile, frame tile) mapping, see gemm_kernel
+    // split-K (gemm_kernel only; optional): partial-accumulator workspace + zero-initialised ticket counters.
+    // The launcher picks ksplit (1 when ws is null or the launch already fills the chip).
+    float* ws;               // >= tiles * ksplit * 128 * BN floats
+    unsigned* ws_cnt;        // >= tiles * 4 counters, all zero between launches
+    size_t ws_floats, ws_cnt_n;
+    int ksplit;              // set by the launcher
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
 };
 

@@ -151,20 +151,27 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // xcd_n != 0 (X-heavy 1x1 GEMMs: small weights, big activations): the 8 M tiles of one frame tile
     // run on the SAME XCD instead, so the X tile is fetched from HBM once per XCD and hits L2 for the
     // other M tiles, while the (small) weight matrix is L2-resident in every XCD.
-    int mt, nt;
+    // Split-K (ksplit > 1, under-filled launches only: few samples / narrow GEMMs): ksplit blocks share
+    // one output tile, each contracts a contiguous range of the K chunks; see the reduction below.
+    int mt, nt, ks;
     if (a.xcd_n) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         mt = idx % a.MT;
-        nt = (idx / a.MT) * 8 + xcd;
+        const int rest = idx / a.MT;
+        ks = rest % a.ksplit;
+        nt = (rest / a.ksplit) * 8 + xcd;
     } else {
         mt = blockIdx.x % a.MT;
-        nt = blockIdx.x / a.MT;
+        const int rest = blockIdx.x / a.MT;
+        ks = rest % a.ksplit;
+        nt = rest / a.ksplit;
     }
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
     const int NS = a.kchunks * a.taps;              // K steps (32 channels x 1 tap each)
-    const int nchunks = a.kchunks / KS;
+    const int cps = a.kchunks / KS / a.ksplit;      // chunks of this block: [c0, c1)
+    const int c0 = ks * cps, c1 = c0 + cps;
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers (LDS-DMA)
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 }
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
-                float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
+                float4* dst = Xs + (((chunk - c0) & 1) * XP + pl) * FW + seg * 64;
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
             }
         };
@@ -217,15 +224,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             }
         }
 #if DR_ABLATE != 9
-        issue(0);
+        issue(c0);
 #endif
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int chunk = c0; chunk < c1; ++chunk) {
             // hand-over #chunk: __syncthreads() waits for this wave's DMA (vmcnt) before the barrier; the
             // consumers' matching barrier opens their chunk.  Only then may the OTHER buffer be refilled
             // (the consumers finished reading it before they arrived here).
             __syncthreads();
 #if DR_ABLATE != 9
-            if (chunk + 1 < nchunks) issue(chunk + 1);
+            if (chunk + 1 < c1) issue(chunk + 1);
 #endif
         }
         return;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                     for (int mi = 0; mi < MI; ++mi) o.v[(g * 3 + pz) * 2 + mi] = src[(g * 3 + pz) * 256 + mi * 32];
             return o;
         };
-        A12 wA = load_a3(0), wB;
+        A12 wA = load_a3(c0 * KS * a.taps), wB;
         const int cen = (a.taps - 1) >> 1;
         const uint4* Xs3 = reinterpret_cast<const uint4*>(Xs);
         // one K step (32 channels x 1 tap): 2 groups x 6 piece products x 2 x NI tiles = 24*NI MFMAs per wave
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             else wB = load_a3(min(slab + 1, NS - 1));
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const uint4* Xb = Xs3 + ((chunk & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+            const uint4* Xb = Xs3 + (((chunk - c0) & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
             uint4 bf[2][3][NW];
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz)
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         using T_ = std::true_type;
         using F_ = std::false_type;
         const int per_chunk = a.taps * KS;
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int chunk = c0; chunk < c1; ++chunk) {
             auto at = [&](auto R, int q) {
                 const int j = q / KS, sub = q - j * KS;
                 step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         return o;
     };
 
-    A8 wA = load_a(0), wB;
+    A8 wA = load_a(c0 * KS * a.taps), wB;
 #if DR_ABLATE >= 1
     wB = load_a(min(1, NS - 1));
 #endif
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         // MFMA stream with sched_group_barrier was measured slower (317 vs 300 us per launch).
         __builtin_amdgcn_sched_barrier(0);
 
-        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+        const float4* Xb = Xs + (((chunk - c0) & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
         float4 bf[2][NW];
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) bf[0][ni] = Xb[ni * 32];
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // tap-major, sub-chunk minor.  Roles alternate A,B,A,...; a chunk always starts in role A (one
     // register copy per chunk when per_chunk is odd).
     const int per_chunk = a.taps * KS;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    for (int chunk = c0; chunk < c1; ++chunk) {
         auto at = [&](auto R, int q) {
             const int j = q / KS, sub = q - j * KS;
             step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
@@ -423,6 +430,57 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 
     const long long tick1 = a.dbg ? clock64() : 0;
+    // ----------------------------------------------------------------------------------------
+    // split-K reduction, per consumer wave (no block-level synchronisation): every wave parks its partial
+    // accumulators in the workspace (fragment order: 1 KiB per store instruction), then takes a ticket on
+    // the counter of its (tile, wave) region.  The wave that draws the last ticket re-reads ALL ksplit
+    // partials in split order - so the sum does not depend on arrival order: results are deterministic -
+    // and runs the epilogue; the others are done.  It also re-arms the counter for the next launch.
+    // The XCDs' L2s are not coherent with each other, so the partials travel with agent-coherent cache
+    // policy (sc0 sc1: write-through stores, L2-bypassing loads) and the ordering is
+    // stores -> s_waitcnt vmcnt(0) -> ticket (agent-scope atomic) -> loads; a full __threadfence() here
+    // costs an L2-wide write-back + invalidate per wave (measured: 25 us per launch).
+    // ----------------------------------------------------------------------------------------
+    if (a.ksplit > 1) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int WQ = NW * 4;                                   // float4 per lane per wave region
+        constexpr int COH = 17;                                      // buffer cache policy: sc0 | sc1
+        const int tile = nt * a.MT + mt;
+        const __amdgpu_buffer_rsrc_t wsr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, 0, (unsigned)(a.ws_floats * 4), 0x00020000);
+        const int sstride = 4 * WQ * 64 * 16;                        // bytes between consecutive splits
+        const int base = ((tile * a.ksplit * 4 + wave) * (WQ * 64) + lane) * 16;
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 v = {__float_as_uint(acc[0][ni][4 * q]), __float_as_uint(acc[0][ni][4 * q + 1]),
+                                 __float_as_uint(acc[0][ni][4 * q + 2]), __float_as_uint(acc[0][ni][4 * q + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, wsr, base + ks * sstride + (ni * 4 + q) * 1024, 0, COH);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // partials are out before the ticket is drawn
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.ws_cnt + tile * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (unsigned)(a.ksplit - 1)) return;
+        if (lane == 0) __hip_atomic_store(a.ws_cnt + tile * 4 + wave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][ni][e] = 0.f;
+        for (int sp = 0; sp < a.ksplit; ++sp) {
+            u32x4 v[WQ];
+#pragma unroll
+            for (int i = 0; i < WQ; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + sp * sstride + i * 1024, 0, COH);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0][ni][4 * q + e] += __uint_as_float(v[ni * 4 + q][e]);
+        }
+    }
     // ----------------------------------------------------------------------------------------
     // epilogue.  C/D fragment of 32x32: column = lane&31 (frame), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
@@ -876,8 +934,19 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil, PREC, EPI);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * tps;
-    const dim3 grid((unsigned)(a.MT * NT));
     GemmArgs b = a;
+    // Split-K for launches that cannot fill the chip: double the split while all blocks still fit in one
+    // round of the 256 CUs, every split keeps >= 1 chunk and the partials fit the workspace.
+    b.ksplit = 1;
+    if (a.ws && a.ws_cnt) {
+        static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
+        const int nchunks = a.kchunks / KS;
+        const long tiles = (long)a.MT * NT;
+        while (b.ksplit * 2 <= ks_max && tiles * b.ksplit * 2 <= 256 && nchunks % (b.ksplit * 2) == 0 &&
+               (size_t)tiles * (b.ksplit * 2) * 128 * BN <= a.ws_floats && (size_t)tiles * 4 <= a.ws_cnt_n)
+            b.ksplit *= 2;
+    }
+    const dim3 grid((unsigned)(a.MT * NT * b.ksplit));
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
     const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;

@@ -215,32 +215,63 @@ def test_full_chain_graph_equals_eager_and_is_deterministic(full_model):
 
 
 def test_batch_shard_invariance_injected_and_philox(full_model):
-    """Each sample's chain is independent: running the two halves of the batch
-    separately gives bitwise the same rolls - with injected noise and with Philox keyed by the
-    global sample index."""
+    """Each sample's chain is independent: running the two halves of the batch separately
+    gives the same rolls - with injected noise and with Philox keyed by the global sample index.  A
+    smaller shard may be contracted in a different order (split-K / tile flavour are chosen per launch
+    geometry), so across DIFFERENT local batch sizes the agreement is fp32 round-off, not bitwise; the
+    bitwise statement for a fixed contraction order is test_batch_shard_bitwise_without_splitk."""
     hp, p, m = full_model
     wav, x, noise = _cfg2_inputs(B=8)
     full, _ = m.sample(x, wav, noise=noise)
     lo, _ = m.sample(x[:4], wav[:4], noise=noise[:, :4])
     hi, _ = m.sample(x[4:], wav[4:], noise=noise[:, 4:])
-    assert torch.equal(full, torch.cat([lo, hi], 0))
+    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_STEP / 4
     full, _ = m.sample(x, wav, seed=7)
     lo, _ = m.sample(x[:4], wav[:4], seed=7, first_sample=0)
     hi, _ = m.sample(x[4:], wav[4:], seed=7, first_sample=4)
-    assert torch.equal(full, torch.cat([lo, hi], 0))
+    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_STEP / 4
+    hi2, _ = m.sample(x[4:], wav[4:], seed=7, first_sample=4)
+    assert torch.equal(hi, hi2)                      # same geometry: bitwise reproducible
     other, _ = m.sample(x, wav, seed=8)
     assert not torch.equal(full, other)
 
 
+def test_batch_shard_bitwise_without_splitk():
+    """With the contraction order pinned (split-K off; the override is read once per process, hence the
+    child process) sharding the batch changes nothing, bit for bit."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r)
+        from oracle import diffroll_ref as R
+        from tests.test_gpu_parity import make_model, _cfg2_inputs
+        hp = dict(R.DEFAULT_HP); hp.update(kernel_size=9, timesteps=20)
+        m = make_model(hp, R.synthetic_params(hp, seed=3), sampler="cfdg_ddpm_x0", w=0.5)
+        wav, x, noise = _cfg2_inputs(B=8, steps=20)
+        full, _ = m.sample(x, wav, noise=noise)
+        lo, _ = m.sample(x[:4], wav[:4], noise=noise[:, :4]); hi, _ = m.sample(x[4:], wav[4:], noise=noise[:, 4:])
+        ok = torch.equal(full, torch.cat([lo, hi], 0))
+        full, _ = m.sample(x, wav, seed=7)
+        lo, _ = m.sample(x[:4], wav[:4], seed=7, first_sample=0); hi, _ = m.sample(x[4:], wav[4:], seed=7, first_sample=4)
+        ok = ok and torch.equal(full, torch.cat([lo, hi], 0))
+        print("BITWISE", int(ok))
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DR_KSPLIT_MAX="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("BITWISE 1"), r.stdout[-500:]
+
+
 def test_cfg_weight_zero_equals_conditional_sampler(full_model):
-    """(1+w) c - w u with w = 0 is c: cfdg_ddpm_x0(w=0) == ddpm_x0 bitwise (task/diffusion.py:953)."""
+    """(1+w) c - w u with w = 0 is c: cfdg_ddpm_x0(w=0) == ddpm_x0 (task/diffusion.py:953).  The two run with
+    different batch geometry (2B vs B evaluations), i.e. possibly different contraction orders: round-off."""
     hp, p, _ = full_model
     wav, x, noise = _cfg2_inputs(B=2, steps=200)
     m0 = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.0)
     m1 = make_model(hp, p, sampler="ddpm_x0")
     a, _ = m0.sample(x, wav, noise=noise)
     b, _ = m1.sample(x, wav, noise=noise)
-    assert torch.equal(a, b)
+    assert maxdiff(a.cpu(), b.cpu()) <= ATOL_STEP / 4
 
 
 def test_philox_noise_is_standard_normal(full_model):
