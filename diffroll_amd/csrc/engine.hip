@@ -287,7 +287,31 @@ int pick_ni(int MT, int NB, int T, int taps, int dil, int prec = 0) {
     return pick_tile(MT, NB, T, taps, dil, prec, EPI_GATE, false).n;
 }
 hipError_t launch_tiled(const GemmArgs& a, int epi, Tile t, hipStream_t s, int prec) {
+    if (t.flavor == 2) return launch_pointwise(a, t.n, s);
     return t.flavor == 1 ? launch_gemm16(a, epi, t.n, s) : launch_gemm(a, epi, t.n, s, prec);
+}
+// tile of the 1x1 residual/skip GEMM: flavor 2 = operands direct from L2 (pw_kernel), fp32 only
+Tile pick_pointwise_tile(int MT, int NB, int T, int prec) {
+    if (prec) return Tile{0, 1};
+    static const int pw = getenv("DR_PW") ? atoi(getenv("DR_PW")) : 1;          // tuning experiments: 0 = LDS-staged kernels
+    static const int pw_ni = getenv("DR_PW_NW") ? atoi(getenv("DR_PW_NW")) : 0;    // force 32*NW-frame blocks
+    if (!pw) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
+    if (pw_ni) return Tile{2, pw_ni};
+    // launches that cannot fill half the chip even with 64-frame blocks: the LDS-staged kernel with split-K
+    if ((long)MT * NB * ((T + 63) / 64) <= 128) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
+    // cost = block rounds over the 256 CUs x frames per block; 64-frame blocks carry a measured 7 % penalty
+    // (twice the operand loads per MFMA)
+    struct Cand { int nw; double pen; };
+    const Cand cands[] = {{4, 1.0}, {5, 1.0}, {3, 1.02}, {2, 1.07}};
+    Tile best{2, 4};
+    double best_cost = 1e30;
+    for (const Cand& c : cands) {
+        const int bn = 32 * c.nw;
+        const long blocks = (long)MT * NB * ((T + bn - 1) / bn);
+        const double cost = (double)((blocks + 255) / 256) * bn * c.pen;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = Tile{2, c.nw}; }
+    }
+    return best;
 }
 // let the launcher split K when the launch under-fills the chip (single clips, narrow projections)
 void allow_splitk(const dr_engine* e, GemmArgs& a) {
@@ -388,7 +412,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
             allow_splitk(e, a);
-            HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), st, prec));
+            HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, pick_pointwise_tile(Cp / 64, NB, T, prec), st, prec));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
@@ -1005,7 +1029,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     }
     a.dbg = e->dbg_ticks;
     allow_splitk(e, a);
-    HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, e->prec ? Tile{0, 1} : pick_tile(Cp / 64, NB, T, 1, 1, 0, EPI_RES_SKIP, true), (hipStream_t)stream, e->prec));
+    HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, pick_pointwise_tile(Cp / 64, NB, T, e->prec), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
 

@@ -83,6 +83,9 @@ hipError_t init_kernels();
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
 // flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5,6}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
 hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
+// 1x1 EPI_RES_SKIP GEMM with both operands direct from L2 (no LDS): block = 128 rows x 32*NW frames
+// (NW in {2,3,4,5}), 256 threads
+hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 
 struct UpdateArgs {

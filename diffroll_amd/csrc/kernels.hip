@@ -469,16 +469,30 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         for (int ni = 0; ni < NW; ++ni)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[0][ni][e] = 0.f;
-        for (int sp = 0; sp < a.ksplit; ++sp) {
-            u32x4 v[WQ];
+        // U splits in flight per wait (the loads are pure latency: ~1.5 us each when taken one by one);
+        // the adds stay in split order whatever U is
+        auto reduce = [&](auto UU, int sp0) {
+            constexpr int U = decltype(UU)::value;
+            u32x4 v[U][WQ];
 #pragma unroll
-            for (int i = 0; i < WQ; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + sp * sstride + i * 1024, 0, COH);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int ni = 0; ni < NW; ++ni)
+                for (int i = 0; i < WQ; ++i)
+                    v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + (sp0 + u) * sstride + i * 1024, 0, COH);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[0][ni][4 * q + e] += __uint_as_float(v[ni * 4 + q][e]);
+                for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[0][ni][4 * q + e] += __uint_as_float(v[u][ni * 4 + q][e]);
+        };
+        constexpr int UMAX = (NW == 2) ? 4 : 2;
+        if (a.ksplit % UMAX == 0) {
+            for (int sp = 0; sp < a.ksplit; sp += UMAX) reduce(std::integral_constant<int, UMAX>{}, sp);
+        } else {
+            for (int sp = 0; sp < a.ksplit; sp += 2) reduce(std::integral_constant<int, 2>{}, sp);
         }
     }
     // ----------------------------------------------------------------------------------------
@@ -632,6 +646,204 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         a.dbg[0] = tick1 - tick0;           // main loop
         a.dbg[1] = clock64() - tick0;       // whole block
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1) GEMM with BOTH operands straight from L2: the 1x1 output projection + residual / skip
+// update (model/diffwave.py:149-151, :680).  A 1x1 GEMM has no tap reuse, so staging X through LDS buys
+// nothing - and costs a hand-over barrier per chunk plus the LDS-DMA traffic, during which the consumers of
+// gemm_kernel were measured to run ~30 % slower (87 vs 66.7 ticks per MFMA).  Here a block is just four
+// consumer waves, 4 (M) x 1 (N), wave tile 32 rows x 32*NW frames: per 32-channel K step a wave loads its
+// 4 A fragments (packed weights, fragment order) and 4*NW B fragments (P4 activations: one float4 = the 4
+// K values of a lane for 4 consecutive MFMAs) one step ahead into the alternate register set, then
+// issues 16*NW MFMAs.  No LDS, no barriers, no producers.  Frames beyond T are clamped (their columns are
+// never written).
+// ---------------------------------------------------------------------------------------------
+template <int NW>     // 32-frame MFMA tiles per wave: block = 128 rows x 32*NW frames
+__global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
+    constexpr int BN = 32 * NW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hi = lane >> 5;
+    const long long tick0 = a.dbg ? clock64() : 0;
+
+    int mt, nt;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        nt = (idx / a.MT) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        nt = blockIdx.x / a.MT;
+    }
+    const int tps = (a.T + BN - 1) / BN;
+    const int b = nt / tps;
+    const int t0 = (nt % tps) * BN;
+    const int NS = a.kchunks;
+
+    // Both operands through buffer loads: resource = (this M tile's weight panel | this sample's X tensor) in
+    // SGPRs, per-lane byte offset fixed for the whole kernel (1 + NW VGPRs), per-step offset scalar - so a
+    // K step costs no vector address arithmetic (flat 64-bit addressing cost ~70 VALU ops per step, i.e.
+    // ~12 of 76 ticks per MFMA, all exposed: nothing else runs on the SIMD).  Out-of-range reads (K padding
+    // planes) return 0 from the bounds check; frames past T read the next plane's data (finite, never used).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Wp + (long)mt * NS * 4096), 0, (unsigned)NS * 16384u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.X + (long)b * a.x_bs), 0, (unsigned)(a.x_planes * a.x_ps * 4), 0x00020000);
+    const int wvo = (hi * 128 + wave * 32 + r) * 16;
+    const int xps = (int)a.x_ps * 4;                          // bytes per plane
+    int xvo[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) xvo[ni] = hi * xps + min(t0 + ni * 32 + r, a.T - 1) * 16;
+
+    struct AF { float4 v[4]; };
+    struct BF { float4 v[4][NW]; };
+    auto asf4 = [](const u32x4 u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
+    auto load_a = [&](int slab) -> AF {
+        AF o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o.v[g] = asf4(__builtin_amdgcn_raw_buffer_load_b128(wr, wvo, slab * 16384 + g * 4096, 0));
+        return o;
+    };
+    auto load_b = [&](int slab) -> BF {
+        BF o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni)
+                o.v[g][ni] = asf4(__builtin_amdgcn_raw_buffer_load_b128(xr, xvo[ni], (slab * 8 + g * 2) * xps, 0));
+        return o;
+    };
+
+    f32x16 acc[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+
+    AF aA = load_a(0), aB;
+    BF bA = load_b(0), bB;
+    auto step = [&](auto ROLE, int slab) {
+        constexpr bool kB = decltype(ROLE)::value;
+        const int nxt = min(slab + 1, NS - 1);
+        if constexpr (kB) { aA = load_a(nxt); bA = load_b(nxt); }
+        else { aB = load_a(nxt); bB = load_b(nxt); }
+        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch issued ahead of the MFMA block
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) {
+                const float4 af = kB ? aB.v[g] : aA.v[g];
+                const float4 bf = kB ? bB.v[g][ni] : bA.v[g][ni];
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[ni], 0, 0, 0);
+                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[ni], 0, 0, 0);
+            }
+    };
+    // epilogue operands (EPI_RES_SKIP): rows [0, y_rows) h = (h + acc + b) / sqrt(2) in place (+ hd = h + d_next),
+    // rows [y_rows, 2 y_rows) skip (+)= acc + b.  The read-modify-write tile comes straight from global and is
+    // requested BEFORE the last two K steps, so its latency hides behind their MFMAs.
+    auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
+    const int rowb = mt * 128 + wave * 32 + 4 * hi;           // + 8q
+    const bool res_rows = rowb < a.y_rows;                     // wave-uniform (y_rows is a multiple of 64)
+    float4 ebias[4], ed2[4], eop[NW][4];
+    auto load_epilogue = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ebias[q] = *reinterpret_cast<const float4*>(a.bias + rowb + 8 * q);
+            ed2[q] = *reinterpret_cast<const float4*>(a.d2 + min(rowb + 8 * q, a.y_rows - 4));
+        }
+        const float* base = res_rows ? a.Y + (long)b * a.y_bs + (long)(rowb >> 2) * a.y_ps
+                                     : a.skip + (long)b * a.s_bs + (long)((rowb - a.y_rows) >> 2) * a.T * 4;
+        const long qs = res_rows ? 2 * a.y_ps : (long)2 * a.T * 4;      // 8 rows = 2 planes further
+        const long fs = res_rows ? a.y_fs : 4;
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const int tc = min(t0 + ni * 32 + r, a.T - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) eop[ni][q] = *reinterpret_cast<const float4*>(base + q * qs + tc * fs);
+        }
+    };
+    int slab = 0;
+    const int pre = max(NS - 2, 0) & ~1;                      // even number of steps before the prefetch point
+    for (; slab < pre; slab += 2) {
+        step(std::false_type{}, slab);
+        step(std::true_type{}, slab + 1);
+    }
+    load_epilogue();
+    __builtin_amdgcn_sched_barrier(0);
+    for (; slab + 2 <= NS; slab += 2) {
+        step(std::false_type{}, slab);
+        step(std::true_type{}, slab + 1);
+    }
+    if (slab < NS) step(std::false_type{}, slab);
+    const long long tick1 = a.dbg ? clock64() : 0;
+
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        const int t = t0 + ni * 32 + r;
+        if (t >= a.T) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p0 = rowb + 8 * q;
+            float v[4], bb[4], pv[4], o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[ni][4 * q + e];
+            f4arr(ebias[q], bb); f4arr(eop[ni][q], pv);
+            if (res_rows) {
+                float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (a.Y2) {
+                    float dd[4];
+                    f4arr(ed2[q], dd);
+                    const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                    if (a.out_s3 & 2) {
+                        store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                    } else {
+                        float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                        *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                    }
+                }
+            } else {
+                float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
+                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.dbg[0] = tick1 - tick0;
+        a.dbg[1] = clock64() - tick0;
+    }
+}
+
+template <int NW>
+static hipError_t launch_pw_t(const GemmArgs& a, hipStream_t s) {
+    const int BN = 32 * NW;
+    const int NT = a.NB * ((a.T + BN - 1) / BN);
+    GemmArgs b = a;
+    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks, xbytes = (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
+    if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
+    hipLaunchKernelGGL((pw_kernel<NW>), dim3((unsigned)(a.MT * NT)), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+// 1x1 EPI_RES_SKIP GEMM, fp32, operands direct from L2; block = 128 rows x 32*NW frames, NW in {2,3,4,5}
+hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s) {
+    if (a.taps != 1 || a.kchunks < 1 || a.x_fs != 4) return hipErrorInvalidValue;
+    switch (NW) {
+        case 2: return launch_pw_t<2>(a, s);
+        case 3: return launch_pw_t<3>(a, s);
+        case 4: return launch_pw_t<4>(a, s);
+        case 5: return launch_pw_t<5>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 // ---------------------------------------------------------------------------------------------
