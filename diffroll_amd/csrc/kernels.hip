@@ -340,65 +340,79 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             }
         }
     } else {
+    // A fragments through buffer loads: the M tile's weight panel is the resource (SGPRs), the per-lane
+    // byte offset is fixed for the whole kernel and the per-step offset is scalar - no vector address
+    // arithmetic in the K loop (with flat 64-bit addresses it was ~12 exposed VALU instructions per step).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Wp + (long)mt * NS * 4096), 0, (unsigned)NS * 16384u, 0x00020000);
+    const int wvo = (hi * 128 + wr * WROWS + r) * 16;
     auto load_a = [&](int slab) -> A8 {
         A8 o;
-        const float4* src = Wg + (long)slab * 1024;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) o.v[g * 2 + mi] = src[g * 256 + mi * 32];
-        return o;
-    };
-
-    A8 wA = load_a(c0 * KS * a.taps), wB;
-#if DR_ABLATE >= 1
-    wB = load_a(min(1, NS - 1));
-#endif
-    const int cen = (a.taps - 1) >> 1;
-
-    // One K step: 64*NI MFMAs per wave.  ROLE (compile time) selects which of the two A-fragment
-    // register sets is consumed; the other one receives the next step's fragments (prefetch distance
-    // one step).  Roles alternate statically so there are no per-step register copies.
-    auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
-        constexpr bool kB = decltype(ROLE)::value;
-#if DR_ABLATE == 0
-        if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
-        else wB = load_a(min(slab + 1, NS - 1));
-#endif
-        // keep the prefetch loads issued HERE, ahead of the MFMA block (hipcc otherwise sinks them to
-        // their first use and exposes the whole L2 latency once per step).  Spreading them through the
-        // MFMA stream with sched_group_barrier was measured slower (317 vs 300 us per launch).
-        __builtin_amdgcn_sched_barrier(0);
-
-        const float4* Xb = Xs + (((chunk - c0) & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
-        float4 bf[2][NW];
-#pragma unroll
-        for (int ni = 0; ni < NW; ++ni) bf[0][ni] = Xb[ni * 32];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int cur = g & 1, nxt = cur ^ 1;
-            if (g < 3) {
-#pragma unroll
-                for (int ni = 0; ni < NW; ++ni) bf[nxt][ni] = Xb[(g + 1) * 2 * FW + ni * 32];
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NW; ++ni) {
-                    const float4 af = kB ? wB.v[g * 2 + mi] : wA.v[g * 2 + mi];
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[cur][ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[cur][ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[cur][ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[cur][ni].w, acc[mi][ni], 0, 0, 0);
-                }
+            const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);
+            o.v[g * 2] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         }
-        // Pin the software pipeline: group g+1's fragment reads are issued BEFORE group g's MFMAs (hipcc
-        // otherwise sinks them below the MFMAs and waits at once, exposing the LDS latency 4x per step).
-        sgb<0x100, NW>();
-        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
-        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
-        sgb<0x100, NW>(); sgb<0x8, 4 * MI * NW>();
-        sgb<0x8, 4 * MI * NW>();
+        return o;
+    };
+    static_assert(MI == 1, "one 32-row MFMA tile per consumer wave");
+
+    A8 wA = load_a(c0 * KS * a.taps), wB;
+    const int cen = (a.taps - 1) >> 1;
+
+    // B fragments of one 8-channel group: NW float4 (one per 32-frame MFMA tile), conflict-free ds_read_b128
+    struct BF { float4 v[NW]; };
+    BF b0, b1;                                   // groups 0/2 and 1/3 of the step in flight
+    auto xaddr = [&](int chunk, int q) -> const float4* {     // X tile address of step q of a chunk
+        const int j = q / KS, sub = q - j * KS;
+        return Xs + (((chunk - c0) & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+    };
+    auto rd = [&](const float4* Xb, int g) -> BF {
+        BF o;
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) o.v[ni] = Xb[g * 2 * FW + ni * 32];
+        return o;
+    };
+    auto mma4 = [&](const float4 af, const BF& bf) {
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[ni].x, acc[0][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.v[ni].y, acc[0][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.v[ni].z, acc[0][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[ni].w, acc[0][ni], 0, 0, 0);
+        }
+    };
+
+    // One K step (32 channels x 1 tap): 16*NW MFMAs per wave in 4 groups of 8 channels.  Software pipeline,
+    // pinned with sched_group_barrier: the fragment reads of group g+1 are issued before group g's MFMAs,
+    // and the reads of the NEXT step's group 0 before this step's group 3 - so inside a chunk no MFMA ever
+    // waits for LDS; only the chunk's first step reads its own group 0, right after the hand-over barrier
+    // (the last step of a chunk prefetches a valid but unused address: the next tile is not staged yet).
+    // ROLE (compile time) selects which of the two A-fragment register sets is consumed; the other receives
+    // the next step's fragments (prefetch distance one step), requested at the top of the step.  Roles
+    // alternate statically: no per-step register copies.
+    const int per_chunk = a.taps * KS;
+    auto step = [&](auto ROLE, int slab, int chunk, int q) {
+        constexpr bool kB = decltype(ROLE)::value;
+        const float4* Xb = xaddr(chunk, q);
+        if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
+        else wB = load_a(min(slab + 1, NS - 1));
+        // keep the A prefetch issued HERE, ahead of the MFMA block (hipcc otherwise sinks it to its first
+        // use and exposes the whole L2 latency once per step)
+        __builtin_amdgcn_sched_barrier(0);
+        b1 = rd(Xb, 1);
+        mma4(kB ? wB.v[0] : wA.v[0], b0);
+        b0 = rd(Xb, 2);
+        mma4(kB ? wB.v[2] : wA.v[2], b1);
+        b1 = rd(Xb, 3);
+        mma4(kB ? wB.v[4] : wA.v[4], b0);
+        b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
+        mma4(kB ? wB.v[6] : wA.v[6], b1);
+        sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
+        sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -406,14 +420,14 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // Steps of a chunk, q = 0 .. per_chunk-1, in memory order of the slabs ([32-channel kchunk][tap]):
     // tap-major, sub-chunk minor.  Roles alternate A,B,A,...; a chunk always starts in role A (one
     // register copy per chunk when per_chunk is odd).
-    const int per_chunk = a.taps * KS;
     for (int chunk = c0; chunk < c1; ++chunk) {
         auto at = [&](auto R, int q) {
             const int j = q / KS, sub = q - j * KS;
-            step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+            step(R, (chunk * KS + sub) * a.taps + j, chunk, q);
         };
         __syncthreads();   // X tile #chunk staged by the producers (matches their hand-over barrier)
         if (a.dbg && blockIdx.x == 0 && tid == 0 && chunk < 14) a.dbg[2 + chunk] = clock64() - tick0;
+        b0 = rd(xaddr(chunk, 0), 0);
         int q = 0;
         for (; q + 2 <= per_chunk; q += 2) {
             at(F_{}, q);
@@ -421,9 +435,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         }
         if (q < per_chunk) {
             at(F_{}, q);
-#if DR_ABLATE == 0
             wA = wB;
-#endif
         }
     }
 
