@@ -86,6 +86,15 @@ template <int MASK, int N>
 DR_DEVINL void sgb() {
     if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
 }
+// N x (2 MFMAs, 1 LDS read): fragment reads issued in the shadow of the running MFMAs
+template <int N>
+DR_DEVINL void sgb_mix() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        sgb_mix<N - 1>();
+    }
+}
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -242,7 +251,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     const int wr = wave / WNC, wc = wave % WNC;
     const int r = lane & 31, hi = lane >> 5;
     // this lane's A fragments inside a slab: fp32 [g][hi][row][4] (16 KiB); S3 [g16][piece][kq][row][8 bf16] (24 KiB)
-    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * (PREC ? 1536 : 1024) + hi * 128 + wr * WROWS + r;
 
     f32x16 acc[MI][NW];
 #pragma unroll
@@ -258,77 +266,93 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     float4 eop[MI][NW][4];
 
     if constexpr (PREC == 1) {
-        const uint4* Wg3 = reinterpret_cast<const uint4*>(Wg);
+        // A fragments through buffer loads with scalar per-step offsets (see the fp32 path): slab = 24 KiB,
+        // [g16 2][piece 3][kq 2][row 128][8 bf16]
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.Wp + (long)mt * NS * 6144), 0, (unsigned)NS * 24576u, 0x00020000);
+        const int wvo = (hi * 128 + wr * WROWS + r) * 16;
+        static_assert(MI == 1, "one 32-row MFMA tile per consumer wave");
         auto load_a3 = [&](int slab) -> A12 {
             A12 o;
-            const uint4* src = Wg3 + (long)slab * 1536;
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int pz = 0; pz < 3; ++pz)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) o.v[(g * 3 + pz) * 2 + mi] = src[(g * 3 + pz) * 256 + mi * 32];
+            for (int gp = 0; gp < 6; ++gp) {
+#if DR_ABLATE == 2          // measurement build: always the same slab (L1-hot A loads)
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, gp * 4096, 0);
+#else
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 24576 + gp * 4096, 0);
+#endif
+                o.v[gp * 2] = make_uint4(u.x, u.y, u.z, u.w);
+            }
             return o;
         };
         A12 wA = load_a3(c0 * KS * a.taps), wB;
+#if DR_ABLATE == 1
+        wB = wA;
+#endif
         const int cen = (a.taps - 1) >> 1;
+        const int per_chunk = a.taps * KS;
         const uint4* Xs3 = reinterpret_cast<const uint4*>(Xs);
-        // one K step (32 channels x 1 tap): 2 groups x 6 piece products x 2 x NI tiles = 24*NI MFMAs per wave
-        auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
+        // B fragments of one 16-channel group: 3 pieces x NW 32-frame tiles
+        struct BF3 { uint4 v[3][NW]; };
+        BF3 b0, b1;
+        auto xaddr = [&](int chunk, int q) -> const uint4* {
+            const int j = q / KS, sub = q - j * KS;
+            return Xs3 + (((chunk - c0) & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
+        };
+        auto rd3 = [&](const uint4* Xb, int g) -> BF3 {
+            BF3 o;
+#pragma unroll
+            for (int pz = 0; pz < 3; ++pz)
+#pragma unroll
+                for (int ni = 0; ni < NW; ++ni) o.v[pz][ni] = Xb[(g * 6 + pz * 2) * FW + ni * 32];
+            return o;
+        };
+        // six piece products per accumulator, smallest terms first; consecutive MFMAs go to different
+        // accumulators (the pinned schedule keeps program order: no dependent back-to-back pairs)
+        auto mma6 = [&](const uint4 a0, const uint4 a1, const uint4 a2, const BF3& bf) {
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a2, bf.v[0][ni], acc[0][ni]);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a0, bf.v[2][ni], acc[0][ni]);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a1, bf.v[1][ni], acc[0][ni]);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a1, bf.v[0][ni], acc[0][ni]);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a0, bf.v[1][ni], acc[0][ni]);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[0][ni] = mma_bf16(a0, bf.v[0][ni], acc[0][ni]);
+        };
+        // One K step (32 channels x 1 tap): 2 groups x 6 piece products x NW tiles = 12*NW MFMAs per wave.
+        // A 32x32x16 bf16 MFMA is 32 cycles, so a step is only 384*NW cycles: every non-MFMA instruction
+        // that is not issued in the shadow of a running MFMA shows.  Pipeline (pinned): the reads of group 1
+        // are interleaved 1:2 with group 0's MFMAs, the reads of the NEXT step's group 0 with group 1's;
+        // only the chunk's first step reads its own group 0 (after the hand-over barrier).
+        auto step = [&](auto ROLE, int slab, int chunk, int q) {
             constexpr bool kB = decltype(ROLE)::value;
-#if DR_ABLATE == 2          // measurement build: always the same slab (L1-hot A loads)
-            if constexpr (kB) wA = load_a3(0); else wB = load_a3(0);
-#elif DR_ABLATE == 1        // measurement build: no A loads at all
-            if constexpr (kB) wA = wB; else wB = wA;
-#else
+            const uint4* Xb = xaddr(chunk, q);
+#if DR_ABLATE != 1          // measurement build 1: no A loads at all
             if constexpr (kB) wA = load_a3(min(slab + 1, NS - 1));
             else wB = load_a3(min(slab + 1, NS - 1));
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const uint4* Xb = Xs3 + (((chunk - c0) & 1) * XP + sub * 12 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
-            uint4 bf[2][3][NW];
-#pragma unroll
-            for (int pz = 0; pz < 3; ++pz)
-#pragma unroll
-                for (int ni = 0; ni < NW; ++ni) bf[0][pz][ni] = Xb[(pz * 2) * FW + ni * 32];
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                if (g == 0) {
-#pragma unroll
-                    for (int pz = 0; pz < 3; ++pz)
-#pragma unroll
-                        for (int ni = 0; ni < NW; ++ni) bf[1][pz][ni] = Xb[(6 + pz * 2) * FW + ni * 32];
-                }
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NW; ++ni) {
-                        const uint4 a0 = kB ? wB.v[(g * 3 + 0) * 2 + mi] : wA.v[(g * 3 + 0) * 2 + mi];
-                        const uint4 a1 = kB ? wB.v[(g * 3 + 1) * 2 + mi] : wA.v[(g * 3 + 1) * 2 + mi];
-                        const uint4 a2 = kB ? wB.v[(g * 3 + 2) * 2 + mi] : wA.v[(g * 3 + 2) * 2 + mi];
-                        // smallest terms first
-                        acc[mi][ni] = mma_bf16(a2, bf[g][0][ni], acc[mi][ni]);
-                        acc[mi][ni] = mma_bf16(a0, bf[g][2][ni], acc[mi][ni]);
-                        acc[mi][ni] = mma_bf16(a1, bf[g][1][ni], acc[mi][ni]);
-                        acc[mi][ni] = mma_bf16(a1, bf[g][0][ni], acc[mi][ni]);
-                        acc[mi][ni] = mma_bf16(a0, bf[g][1][ni], acc[mi][ni]);
-                        acc[mi][ni] = mma_bf16(a0, bf[g][0][ni], acc[mi][ni]);
-                    }
-            }
-            // pin the software pipeline (see the fp32 path): both groups' fragment reads first
-            sgb<0x100, 3 * NW>();
-            sgb<0x100, 3 * NW>(); sgb<0x8, 6 * MI * NW>();
-            sgb<0x8, 6 * MI * NW>();
+            b1 = rd3(Xb, 1);
+            mma6(kB ? wB.v[0] : wA.v[0], kB ? wB.v[2] : wA.v[2], kB ? wB.v[4] : wA.v[4], b0);
+            b0 = rd3(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
+            mma6(kB ? wB.v[6] : wA.v[6], kB ? wB.v[8] : wA.v[8], kB ? wB.v[10] : wA.v[10], b1);
+            sgb_mix<3 * NW>();
+            sgb_mix<3 * NW>();
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
-        const int per_chunk = a.taps * KS;
         for (int chunk = c0; chunk < c1; ++chunk) {
             auto at = [&](auto R, int q) {
                 const int j = q / KS, sub = q - j * KS;
-                step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+                step(R, (chunk * KS + sub) * a.taps + j, chunk, q);
             };
             __syncthreads();
+            b0 = rd3(xaddr(chunk, 0), 0);
             int q = 0;
             for (; q + 2 <= per_chunk; q += 2) {
                 at(F_{}, q);
