@@ -259,7 +259,7 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
     static const char* forced = getenv("DR_TILE");     // tuning experiments: "32:2", "16:5", ... (if it fits)
     const int halo = ((taps - 1) / 2) * dil;
     struct Cand { int flavor, n, bn; double pen; };
-    const Cand cands[] = {{0, 2, 128, 1.0}, {1, 5, 160, 1.04}, {1, 6, 192, 1.04}, {1, 3, 96, 1.04}, {0, 1, 64, 1.0}};
+    const Cand cands[] = {{0, 2, 128, 1.0}, {1, 5, 160, 1.04}, {1, 3, 96, 1.04}, {0, 1, 64, 1.0}};
     auto feasible = [&](const Cand& c) {
         if (c.flavor == 1 && (!allow16 || prec != 0)) return false;
         const int ks = (taps == 1) ? 2 : 1;

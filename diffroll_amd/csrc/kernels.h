@@ -81,7 +81,7 @@ struct GemmArgs {
 hipError_t init_kernels();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
-// flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5,6}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
+// flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
 hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 // 1x1 EPI_RES_SKIP GEMM with both operands direct from L2 (no LDS): block = 128 rows x 32*NW frames
 // (NW in {2,3,4,5}), 256 threads

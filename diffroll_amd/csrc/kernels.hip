@@ -4,7 +4,7 @@
 // the LDS-DMA producers, the P4 / S3 activation layouts and the packed weights:
 //   gemm_kernel<.., PREC=0>  exact fp32 on v_mfma_f32_32x32x2_f32      (default; 64/128-frame blocks)
 //   gemm_kernel<.., PREC=1>  split-bf16 on v_mfma_f32_32x32x16_bf16    (opt-in "bf16x3", hot kernels)
-//   gemm16_kernel            exact fp32 on v_mfma_f32_16x16x4_f32      (96/160/192-frame blocks, hot kernels)
+//   gemm16_kernel            exact fp32 on v_mfma_f32_16x16x4_f32      (96/160-frame blocks, hot kernels)
 // used for
 //   * dilated Conv1d (k taps) + conditioner add + sigmoid*tanh gate   (model/diffwave.py:139-147)
 //   * 1x1 output projection + residual/skip update (+ h + d_next)      (model/diffwave.py:149-151, :138)
@@ -884,7 +884,7 @@ hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 // Flexible-width variant on v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue): 16-frame column tiles,
-// so a block covers BN = 32*NJ frames for any NJ (96, 160, 192 ...).  Used when 64/128-frame tiles
+// so a block covers BN = 32*NJ frames (96, 160).  Used when 64/128-frame tiles
 // quantise badly over the 256 CUs (config 5: 8 x 640 frames -> 4 x 160-frame tiles per clip = exactly
 // 256 blocks instead of 2.5 rounds of 64-frame blocks).  Same packed weights (the slab is
 // [channel/4][row][4], which serves both MFMA shapes), same LDS-DMA producers, same P4 layouts.
@@ -973,69 +973,84 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
     // rows (l>>4)*4 + reg -> one float4 of the P4 layout per tile.
     const int wr = wave / WNC, wc = wave % WNC;
     const int li = lane & 15, kq = lane >> 4;
-    const float4* Wg = reinterpret_cast<const float4*>(a.Wp) + (long)mt * NS * 1024 + kq * 128 + wr * WROWS + li;
-
     float4 acc[RT][CT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f4zero();
 
+    // A fragments through buffer loads with scalar per-step offsets (as in gemm_kernel)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Wp + (long)mt * NS * 4096), 0, (unsigned)NS * 16384u, 0x00020000);
+    const int wvo = (kq * 128 + wr * WROWS + li) * 16;
     struct AF { float4 v[2 * RT]; };   // [g16][rt]
     auto load_a = [&](int slab) -> AF {
         AF o;
-        const float4* src = Wg + (long)slab * 1024;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) o.v[g * RT + rt] = src[g * 512 + rt * 16];
+            for (int rt = 0; rt < RT; ++rt) {
+                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 8192 + rt * 256, 0);
+                o.v[g * RT + rt] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+            }
         return o;
     };
     AF wA = load_a(0), wB;
     const int cen = (a.taps - 1) >> 1;
+    const int per_chunk = a.taps * KS;
     typedef float v4f __attribute__((ext_vector_type(4)));
 
-    auto step = [&](auto ROLE, int slab, int chunk, int sub, int j) {
+    // B fragments of one 16-channel group: CT float4 (one per 16-frame column tile)
+    struct BF { float4 v[CT]; };
+    BF b0, b1;
+    auto xaddr = [&](int chunk, int q) -> const float4* {
+        const int j = q / KS, sub = q - j * KS;
+        return Xs + ((chunk & 1) * XP + sub * 8 + kq) * FW + halo + (j - cen) * a.dil + wc * WFR + li;
+    };
+    auto rd = [&](const float4* Xb, int g) -> BF {
+        BF o;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) o.v[ct] = Xb[g * 4 * FW + ct * 16];
+        return o;
+    };
+    auto mma = [&](const float4 af, const BF& bf, int rt) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            v4f c = {acc[rt][ct].x, acc[rt][ct].y, acc[rt][ct].z, acc[rt][ct].w};
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.v[ct].x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.v[ct].y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.v[ct].z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.v[ct].w, c, 0, 0, 0);
+            acc[rt][ct] = make_float4(c[0], c[1], c[2], c[3]);
+        }
+    };
+    // K step = 2 groups of 16 channels; group 1's fragments are read before group 0's MFMAs, the NEXT step's
+    // group 0 before group 1's MFMAs (cross-step prefetch inside a chunk, as in gemm_kernel)
+    auto step = [&](auto ROLE, int slab, int chunk, int q) {
         constexpr bool kB = decltype(ROLE)::value;
+        const float4* Xb = xaddr(chunk, q);
         if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
         else wB = load_a(min(slab + 1, NS - 1));
         __builtin_amdgcn_sched_barrier(0);
-        const float4* Xb = Xs + ((chunk & 1) * XP + sub * 8 + kq) * FW + halo + (j - cen) * a.dil + wc * WFR + li;
-        float4 bf[2][CT];
+        b1 = rd(Xb, 1);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) bf[0][ct] = Xb[ct * 16];
+        for (int rt = 0; rt < RT; ++rt) mma(kB ? wB.v[rt] : wA.v[rt], b0, rt);
+        b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if (g == 0) {
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) bf[1][ct] = Xb[4 * FW + ct * 16];
-            }
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float4 af = kB ? wB.v[g * RT + rt] : wA.v[g * RT + rt];
-                    v4f c = {acc[rt][ct].x, acc[rt][ct].y, acc[rt][ct].z, acc[rt][ct].w};
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf[g][ct].x, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf[g][ct].y, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf[g][ct].z, c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf[g][ct].w, c, 0, 0, 0);
-                    acc[rt][ct] = make_float4(c[0], c[1], c[2], c[3]);
-                }
-        }
-        sgb<0x100, CT>();
+        for (int rt = 0; rt < RT; ++rt) mma(kB ? wB.v[RT + rt] : wA.v[RT + rt], b1, rt);
         sgb<0x100, CT>(); sgb<0x8, 4 * RT * CT>();
-        sgb<0x8, 4 * RT * CT>();
+        sgb<0x100, CT>(); sgb<0x8, 4 * RT * CT>();
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    const int per_chunk = a.taps * KS;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         auto at = [&](auto R, int q) {
             const int j = q / KS, sub = q - j * KS;
-            step(R, (chunk * KS + sub) * a.taps + j, chunk, sub, j);
+            step(R, (chunk * KS + sub) * a.taps + j, chunk, q);
         };
         __syncthreads();
+        b0 = rd(xaddr(chunk, 0), 0);
         int q = 0;
         for (; q + 2 <= per_chunk; q += 2) {
             at(F_{}, q);
@@ -1143,17 +1158,16 @@ static hipError_t launch_gemm16_t(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm16_kernel<NJ, KS, EPI>), dim3((unsigned)(a.MT * NT)), dim3(512), lds, s, b);
     return hipGetLastError();
 }
-// frames per block = 32 * NJ; NJ in {3, 5, 6}: 96 / 160 / 192 (64 and 128 are served by gemm_kernel)
+// frames per block = 32 * NJ; NJ in {3, 5}: 96 / 160 (64 and 128 are served by gemm_kernel; 192 does not fit the
+// 256-register budget of a 512-thread block without spilling)
 hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s) {
     if (a.kchunks < 1) return hipErrorInvalidValue;
     if (epi == EPI_GATE) {
         if (NJ == 3) return launch_gemm16_t<3, 1, EPI_GATE>(a, s);
         if (NJ == 5) return launch_gemm16_t<5, 1, EPI_GATE>(a, s);
-        if (NJ == 6) return launch_gemm16_t<6, 1, EPI_GATE>(a, s);
     } else if (epi == EPI_RES_SKIP && a.taps == 1 && a.kchunks % 2 == 0) {
         if (NJ == 3) return launch_gemm16_t<3, 2, EPI_RES_SKIP>(a, s);
         if (NJ == 5) return launch_gemm16_t<5, 2, EPI_RES_SKIP>(a, s);
-        if (NJ == 6) return launch_gemm16_t<6, 2, EPI_RES_SKIP>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -1163,8 +1177,8 @@ static hipError_t init_gemm16() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_kernel<NJ, KS, EPI>),            \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) \
         return e;
-    DR_INIT16(3, 1, EPI_GATE) DR_INIT16(5, 1, EPI_GATE) DR_INIT16(6, 1, EPI_GATE)
-    DR_INIT16(3, 2, EPI_RES_SKIP) DR_INIT16(5, 2, EPI_RES_SKIP) DR_INIT16(6, 2, EPI_RES_SKIP)
+    DR_INIT16(3, 1, EPI_GATE) DR_INIT16(5, 1, EPI_GATE)
+    DR_INIT16(3, 2, EPI_RES_SKIP) DR_INIT16(5, 2, EPI_RES_SKIP)
 #undef DR_INIT16
     return hipSuccess;
 }

@@ -460,7 +460,7 @@ def test_roll_longer_than_spectrogram_is_trimmed(full_model):
 
 
 def test_flexible_width_tiles_vs_oracle(monkeypatch):
-    """The 16x16-MFMA flexible-width kernels (96 / 160 / 192-frame blocks) are chosen by shape; force each
+    """The 16x16-MFMA flexible-width kernels (96 / 160-frame blocks) are chosen by shape; force each
     one and hold it to the oracle on a shape that exercises ragged tails and every dilation."""
     import subprocess, sys, textwrap
     # the tile override is read once per process: run each forced variant in a child process
@@ -485,7 +485,7 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
             worst = max(worst, float((out.cpu() - ref).abs().max()), float((step.cpu() - ref_step).abs().max()))
         print("WORST", worst)
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for tile in ("16:3", "16:5", "16:6", "32:2", "32:1"):
+    for tile in ("16:3", "16:5", "32:2", "32:1"):
         env = dict(os.environ, DR_TILE=tile)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tile, r.stderr[-2000:])
