@@ -95,6 +95,16 @@ DR_DEVINL void sgb_mix() {
         sgb_mix<N - 1>();
     }
 }
+// (x + residual) / math.sqrt(2.0) (model/diffwave.py:151) is an IEEE fp32 division by fp32(sqrt 2) in ATen.
+// For a constant divisor the correctly rounded quotient takes three instructions (Markstein): q = RN(x y),
+// r = x - q d (exact, fma), q' = RN(q + r y) with y = RN(1/d) - verified bit-identical to x / d over every
+// fp32 significand - instead of the ~10-instruction v_div_scale / v_div_fmas / v_div_fixup sequence.
+DR_DEVINL float div_sqrt2(float x) {
+    constexpr float d = 1.41421356237309504880f, y = 1.0f / d;
+    const float q = x * y;
+    const float r = fmaf(-q, d, x);
+    return fmaf(r, y, q);
+}
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate of the residual block (model/diffwave.py:146-147) on the hardware transcendentals: v_exp_f32 (2^x) and
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                         if (p0 < a.y_rows) {   // h = (h + (acc + b)) / sqrt(2), in place (:151)
                             float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                            for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
                             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                             if (a.Y2) {        // hd = h + d_{l+1}: the next dilated conv's input (:139)
                                 float dd[4];
@@ -841,7 +851,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
             if (res_rows) {
                 float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
                 *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                 if (a.Y2) {
                     float dd[4];
@@ -1131,7 +1141,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
                 if (p0 < a.y_rows) {
                     float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (pv[e] + (v[e] + bb[e])) / 1.41421356237309504880f;
+                    for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
                     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                     if (a.Y2) {
                         float dd[4];
