@@ -105,6 +105,15 @@ DR_DEVINL float div_sqrt2(float x) {
     const float r = fmaf(-q, d, x);
     return fmaf(r, y, q);
 }
+// N x (PER MFMAs, 1 vector-memory read)
+template <int N, int PER>
+DR_DEVINL void sgb_spread() {
+    if constexpr (N > 0) {
+        __builtin_amdgcn_sched_group_barrier(0x8, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        sgb_spread<N - 1, PER>();
+    }
+}
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate of the residual block (model/diffwave.py:146-147) on the hardware transcendentals: v_exp_f32 (2^x) and
@@ -442,9 +451,6 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         const float4* Xb = xaddr(chunk, q);
         if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
         else wB = load_a(min(slab + 1, NS - 1));
-        // keep the A prefetch issued HERE, ahead of the MFMA block (hipcc otherwise sinks it to its first
-        // use and exposes the whole L2 latency once per step)
-        __builtin_amdgcn_sched_barrier(0);
         b1 = rd(Xb, 1);
         mma4(kB ? wB.v[0] : wA.v[0], b0);
         b0 = rd(Xb, 2);
@@ -453,7 +459,10 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         mma4(kB ? wB.v[4] : wA.v[4], b0);
         b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
         mma4(kB ? wB.v[6] : wA.v[6], b1);
-        sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
+        // pinned schedule: the 4 A-fragment loads ride inside group 0's MFMAs (one per NW MFMAs: issued in the
+        // shadow of a running MFMA instead of as a burst with the matrix pipe idle; hipcc on its own sinks them
+        // to their first use and exposes the whole L2 latency once per step)
+        sgb<0x100, NW>(); sgb_spread<4, NW>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>();
@@ -785,7 +794,6 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
         const int nxt = min(slab + 1, NS - 1);
         if constexpr (kB) { aA = load_a(nxt); bA = load_b(nxt); }
         else { aB = load_a(nxt); bB = load_b(nxt); }
-        __builtin_amdgcn_sched_barrier(0);       // keep the prefetch issued ahead of the MFMA block
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -797,6 +805,12 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
                 acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[ni], 0, 0, 0);
                 acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[ni], 0, 0, 0);
             }
+        // pinned schedule: the 4 + 4*NW prefetch loads are spread through the MFMA stream (one per PER MFMAs),
+        // so each is issued in the shadow of a running MFMA; issued as one burst at the top of the step they
+        // cost 16 TA cycles each with the matrix pipe idle (71.8 vs 67.6 ticks per MFMA)
+        constexpr int NLD = 4 + 4 * NW, PER = (16 * NW) / NLD;
+        sgb_spread<NLD, PER>();
+        sgb<0x8, 16 * NW - NLD * PER>();
     };
     // epilogue operands (EPI_RES_SKIP): rows [0, y_rows) h = (h + acc + b) / sqrt(2) in place (+ hd = h + d_next),
     // rows [y_rows, 2 y_rows) skip (+)= acc + b.  The read-modify-write tile comes straight from global and is
