@@ -86,13 +86,15 @@ template <int MASK, int N>
 DR_DEVINL void sgb() {
     if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
 }
-// N x (2 MFMAs, 1 LDS read): fragment reads issued in the shadow of the running MFMAs
-template <int N>
+// N x (2 MFMAs, 1 LDS read [, 1 vector-memory read for the first V]): fragment reads and prefetch loads issued
+// in the shadow of the running MFMAs
+template <int N, int V>
 DR_DEVINL void sgb_mix() {
     if constexpr (N > 0) {
         __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        sgb_mix<N - 1>();
+        if constexpr (V > 0) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        sgb_mix<N - 1, (V > 0 ? V - 1 : 0)>();
     }
 }
 // (x + residual) / math.sqrt(2.0) (model/diffwave.py:151) is an IEEE fp32 division by fp32(sqrt 2) in ATen.
@@ -365,13 +367,16 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             if constexpr (kB) wA = load_a3(min(slab + 1, NS - 1));
             else wB = load_a3(min(slab + 1, NS - 1));
 #endif
-            __builtin_amdgcn_sched_barrier(0);
             b1 = rd3(Xb, 1);
             mma6(kB ? wB.v[0] : wA.v[0], kB ? wB.v[2] : wA.v[2], kB ? wB.v[4] : wA.v[4], b0);
             b0 = rd3(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
             mma6(kB ? wB.v[6] : wA.v[6], kB ? wB.v[8] : wA.v[8], kB ? wB.v[10] : wA.v[10], b1);
-            sgb_mix<3 * NW>();
-            sgb_mix<3 * NW>();
+#if DR_ABLATE == 1
+            sgb_mix<3 * NW, 0>();
+#else
+            sgb_mix<3 * NW, 6>();           // + the 6 A-fragment loads of the next step, one per MFMA pair
+#endif
+            sgb_mix<3 * NW, 0>();
         };
         using T_ = std::true_type;
         using F_ = std::false_type;
@@ -1066,14 +1071,14 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
         const float4* Xb = xaddr(chunk, q);
         if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
         else wB = load_a(min(slab + 1, NS - 1));
-        __builtin_amdgcn_sched_barrier(0);
         b1 = rd(Xb, 1);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) mma(kB ? wB.v[rt] : wA.v[rt], b0, rt);
         b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) mma(kB ? wB.v[RT + rt] : wA.v[RT + rt], b1, rt);
-        sgb<0x100, CT>(); sgb<0x8, 4 * RT * CT>();
+        // the 2*RT A-fragment loads of the next step ride inside group 0's MFMAs
+        sgb<0x100, CT>(); sgb_spread<2 * RT, (4 * RT * CT) / (2 * RT)>();
         sgb<0x100, CT>(); sgb<0x8, 4 * RT * CT>();
     };
     using T_ = std::true_type;
