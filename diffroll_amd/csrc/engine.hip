@@ -1021,6 +1021,12 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     }
     p4_out(a, e->h, P, T, Cp);
     a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = 0;
+    {   // second output as in the chain: hd = h + d_{l+1} (fp32 P4 or split-bf16)
+        const long act_bs = (long)Cp * T;
+        a.d2 = e->d_dtab + (size_t)((layer + 1) % e->L) * Cp;
+        if (e->prec) { a.Y2 = e->hd3; a.y2_bs = act_bs + act_bs / 2; a.out_s3 = 2; }
+        else { a.Y2 = e->hd; a.y2_bs = act_bs; }
+    }
     if (!e->dbg_ticks) {
         void* q = nullptr;
         HIPCHK(e, hipMalloc(&q, 16 * sizeof(long long)));

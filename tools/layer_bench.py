@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--uncond", action="store_true", help="all samples unconditional (generation)")
     ap.add_argument("--pointwise", action="store_true", help="time the 1x1 output projection kernel instead")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--cycle", action="store_true",
+                    help="time the layers round-robin (every launch streams a different layer's weights and conditioner "
+                         "from HBM, as inside the sampling chain) instead of one L2-hot layer at a time")
     args = ap.parse_args()
     hp = dict(bench.HP)
     hp["kernel_size"] = args.k
@@ -36,12 +39,15 @@ def main():
     n_cond = 0 if args.uncond else args.B
     if n_cond:
         eng.frontend(wav, args.T)
-    # fill the hidden state with something non-trivial: one real forward
+    # fill EVERY sample slot of the hidden state with real activations (one real evaluation of the same batch
+    # geometry): MFMA power - and with it the clock - depends on the data, half-zero inputs flatter the kernel
     x = torch.randn(args.B, args.T, 88, device=dev)
     if n_cond:
-        eng.forward(x, 100, uncond=False)
+        eng.step("cfdg_ddpm_x0", x.clone(), None, 100, w=0.5)
+    else:
+        eng.forward(x, 100, uncond=True)
     flops = 2.0 * 512 * 1024 * args.k * NB * args.T
-    if args.pointwise:
+    if args.pointwise and not args.cycle:
         flops = 2.0 * 512 * 1024 * NB * args.T
         for layer in [int(v) for v in args.layers.split(",")]:
             for _ in range(5):
@@ -59,6 +65,26 @@ def main():
             nmfma = 64 * (hp["residual_channels"] // 32)
             print(f"1x1 layer {layer:2d} NB={NB} T={args.T}: {us:8.2f} us  {flops / us / 1e6:7.2f} TFLOP/s | block0 ticks: "
                   f"loop {lt} total {bt} ({bt / 2.33e3:.1f} us at 2.33 GHz), loop ticks/MFMA {lt / nmfma:.1f}", flush=True)
+        return
+    if args.cycle:
+        layers = [int(v) for v in args.layers.split(",")]
+        for layer in layers:
+            eng.bench_layer(layer, NB, args.T, 100, n_cond)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            for layer in layers:
+                if args.pointwise:            # 1x1 -> conv -> 1x1 ... as in the chain (time is per PAIR then)
+                    eng.bench_pointwise(layer, NB, args.T)
+                eng.bench_layer(layer, NB, args.T, 100, n_cond)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (args.iters * len(layers))
+        lt, bt = eng.debug_ticks()
+        print(f"round-robin over layers {layers} k={args.k} NB={NB} T={args.T}: {us:8.2f} us per launch  "
+              f"{flops / us / 1e6:7.2f} TFLOP/s | last conv launch, block 0: loop {lt} total {bt} ticks", flush=True)
         return
     for layer in [int(v) for v in args.layers.split(",")]:
         for _ in range(5):
