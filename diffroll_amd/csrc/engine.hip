@@ -396,9 +396,16 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             p4_out(a, e->g, P, T, Cp);
             if (prec) { a.Y = e->g3; a.y_bs = s3_bs; a.out_s3 = 1; }
             allow_splitk(e, a);
-            const bool timed = e->prof && e->prof_used < e->prof_events.size();
+            // Classifier-free guidance evaluates the same x_t twice (samples b and b + bmod): in the first layer
+            // both halves convolve the same h + d_0, so the contraction is done once per pair and the epilogue
+            // writes both gated outputs (conditioner of b / constant unconditional bias).  Bit-identical.
+            const bool dual = (l == 0 && bmod > 0 && NB == 2 * bmod && n_cond == bmod);
+            if (dual) { a.NB = bmod; a.dual = bmod; }
+            const Tile tile = dual ? pick_tile(Cp / 64, bmod, T, e->K, w.dil, prec, EPI_GATE, false)
+                                   : pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true);
+            const bool timed = e->prof && !dual && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-            HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true), st, prec));
+            HIPCHK(e, launch_tiled(a, EPI_GATE, tile, st, prec));
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
         }
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)

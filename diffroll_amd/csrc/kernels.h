@@ -63,6 +63,8 @@ struct GemmArgs {
                              // of at least one sample even when n_cond == 0 (prefetched unconditionally, then ignored)
     long c_bs;
     int n_cond;
+    int dual;                // EPI_GATE, gemm_kernel only: > 0 = also write sample b + dual from the same accumulators
+                             // with the unconditional bias (first layer under classifier-free guidance); NB counts b only
     float* skip;             // EPI_RES_SKIP: P4 [NB][MT/2*32 planes][T][4]
     long s_bs;
     int skip_init;           // 1: skip = value, 0: skip += value

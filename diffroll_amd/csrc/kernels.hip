@@ -570,140 +570,149 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // => per register quad q a lane owns 4 consecutive rows 8q+4hi..+3 = one float4 of the P4 layout.
     // ----------------------------------------------------------------------------------------
     auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
-    float4 ebias[MI][4];                        // [mi][q]
-    float4 ed2[MI][4];                          // second-output offset (step embedding of the next conv)
-    {
-        const float* bsrc = a.bias;
-        if constexpr (EPI == EPI_GATE) bsrc = (b < a.n_cond) ? a.bias : a.bias2;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                ebias[mi][q] = *reinterpret_cast<const float4*>(bsrc + mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi);
-        if constexpr (EPI == EPI_RELU || EPI == EPI_RES_SKIP) {
-#pragma unroll
+    // Dual-output mode (EPI_GATE, a.dual = B > 0): classifier-free guidance feeds the SAME x_t to the conditional
+    // and the unconditional evaluation, so in the first residual layer the dilated conv of sample b and of
+    // sample b + B is the same contraction - it is done once, and the epilogue runs twice (conditioner of
+    // sample b / constant unconditional bias) writing both samples' gated outputs.
+    const int npass = (EPI == EPI_GATE && a.dual > 0) ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < npass; ++pass) {
+        const int be = b + pass * a.dual;
+        float4 ebias[MI][4];                        // [mi][q]
+        float4 ed2[MI][4];                          // second-output offset (step embedding of the next conv)
+        {
+            const float* bsrc = a.bias;
+            if constexpr (EPI == EPI_GATE) bsrc = (be < a.n_cond) ? a.bias : a.bias2;
+    #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    // residual rows only exist below y_rows; the clamp keeps the (unused) skip-row loads in range
-                    const int p0 = min(mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
-                    ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + p0);
-                }
-        }
-    }
-#pragma unroll
-    for (int ni = 0; ni < NW; ++ni) {
-        const int t = t0 + wc * WFR + ni * 32 + r;
-        if constexpr (EPI == EPI_RES_SKIP) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
+    #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    eop[mi][ni][q] = Rs[(wr * (WROWS / 4) + mi * 8 + 2 * q + hi) * BN + wc * WFR + ni * 32 + r];
-        }
-        if constexpr (EPI == EPI_GATE) {
-            // conditioner quads of this frame column: one unconditional batch (unconditional samples read
-            // sample 0's tensor - valid memory - and ignore it)
-            const int tc = min(t, a.T - 1);
-            const float* cb = a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs + (long)tc * 4;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int p0 = mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi;
-                    eop[mi][ni][q] = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
-                }
-        }
-        if (t >= a.T) continue;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rq = 8 * q + 4 * hi;   // row offset inside a 32-row MFMA tile
-            if constexpr (PAIRED) {
-                if (q >= 2) continue;                     // quads 0,1 = gate / cos rows, quads 2,3 = their partners
-                const int c0 = mt * 64 + wr * 16 + rq;    // output channel of the quad (rq = 8q + 4hi < 16)
-                if (c0 >= a.y_rows) continue;
-                float v0[4], v1[4], o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[0][ni][4 * (q + 2) + e]; }
-                if constexpr (EPI == EPI_GATE) {
-                    // y = conv + b_conv + (Wc spec + bc)   [model/diffwave.py:143-144]; unconditional samples
-                    // carry the constant conditioner inside bias2
-                    float b0[4], b1[4], c0v[4], c1v[4];
-                    f4arr(ebias[0][q], b0); f4arr(ebias[0][q + 2], b1);
-                    f4arr(eop[0][ni][q], c0v); f4arr(eop[0][ni][q + 2], c1v);
-                    const bool has_c = b < a.n_cond;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
-                        const float a1 = has_c ? b1[e] + c1v[e] : b1[e];
-                        o[e] = gatef_(v0[e] + a0, v1[e] + a1);   // gate = first half, filter = second (:146-147)
+                    ebias[mi][q] = *reinterpret_cast<const float4*>(bsrc + mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi);
+            if constexpr (EPI == EPI_RELU || EPI == EPI_RES_SKIP) {
+    #pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        // residual rows only exist below y_rows; the clamp keeps the (unused) skip-row loads in range
+                        const int p0 = min(mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
+                        ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + p0);
                     }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
-                }
-                if (a.out_s3 & 1) {   // g for the split-bf16 1x1 kernel
-                    store_s3_quad(a.Y + (long)b * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
-                } else {
-                    float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            } else {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int p0 = mt * 128 + wr * WROWS + mi * 32 + rq;
-                    float v[4], bb[4], o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
-                    f4arr(ebias[mi][q], bb);
-                    if constexpr (EPI == EPI_RES_SKIP) {
-                        float pv[4];
-                        f4arr(eop[mi][ni][q], pv);
-                        // packed rows [0, y_rows) are the residual half, [y_rows, 2*y_rows) the skip half
-                        // (y_rows is a multiple of 64, so the branch is wave-uniform)
-                        if (p0 < a.y_rows) {   // h = (h + (acc + b)) / sqrt(2), in place (:151)
-                            float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
-                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                            if (a.Y2) {        // hd = h + d_{l+1}: the next dilated conv's input (:139)
-                                float dd[4];
-                                f4arr(ed2[mi][q], dd);
-                                const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
-                                if (a.out_s3 & 2) {
-                                    store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
-                                } else {
-                                    float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                                    *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-                                }
-                            }
-                        } else {               // skip (+)= acc + b (:680)
-                            float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
-                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    #pragma unroll
+        for (int ni = 0; ni < NW; ++ni) {
+            const int t = t0 + wc * WFR + ni * 32 + r;
+            if constexpr (EPI == EPI_RES_SKIP) {
+    #pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        eop[mi][ni][q] = Rs[(wr * (WROWS / 4) + mi * 8 + 2 * q + hi) * BN + wc * WFR + ni * 32 + r];
+            }
+            if constexpr (EPI == EPI_GATE) {
+                // conditioner quads of this frame column: one unconditional batch (unconditional samples read
+                // sample 0's tensor - valid memory - and ignore it)
+                const int tc = min(t, a.T - 1);
+                const float* cb = a.cond + (long)(be < a.n_cond ? be : 0) * a.c_bs + (long)tc * 4;
+    #pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int p0 = mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi;
+                        eop[mi][ni][q] = *reinterpret_cast<const float4*>(cb + (long)(p0 >> 2) * a.T * 4);
+                    }
+            }
+            if (t >= a.T) continue;
+    #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rq = 8 * q + 4 * hi;   // row offset inside a 32-row MFMA tile
+                if constexpr (PAIRED) {
+                    if (q >= 2) continue;                     // quads 0,1 = gate / cos rows, quads 2,3 = their partners
+                    const int c0 = mt * 64 + wr * 16 + rq;    // output channel of the quad (rq = 8q + 4hi < 16)
+                    if (c0 >= a.y_rows) continue;
+                    float v0[4], v1[4], o[4];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = acc[0][ni][4 * q + e]; v1[e] = acc[0][ni][4 * (q + 2) + e]; }
+                    if constexpr (EPI == EPI_GATE) {
+                        // y = conv + b_conv + (Wc spec + bc)   [model/diffwave.py:143-144]; unconditional samples
+                        // carry the constant conditioner inside bias2
+                        float b0[4], b1[4], c0v[4], c1v[4];
+                        f4arr(ebias[0][q], b0); f4arr(ebias[0][q + 2], b1);
+                        f4arr(eop[0][ni][q], c0v); f4arr(eop[0][ni][q + 2], c1v);
+                        const bool has_c = be < a.n_cond;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
+                            const float a1 = has_c ? b1[e] + c1v[e] : b1[e];
+                            o[e] = gatef_(v0[e] + a0, v1[e] + a1);   // gate = first half, filter = second (:146-147)
                         }
                     } else {
-                        if (p0 >= a.y_rows) continue;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if constexpr (EPI == EPI_PLAIN) o[e] = a.alpha * v[e] + bb[e];
-                            else if constexpr (EPI == EPI_RELU) o[e] = fmaxf(a.alpha * v[e] + bb[e], 0.f);
-                            else if constexpr (EPI == EPI_SILU) { const float z = v[e] + bb[e]; o[e] = z * sigmoidf_(z); }
-                            else o[e] = logf(v[e] + 1e-6f);
-                        }
-                        float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
+                    }
+                    if (a.out_s3 & 1) {   // g for the split-bf16 1x1 kernel
+                        store_s3_quad(a.Y + (long)be * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
+                    } else {
+                        float* dst = a.Y + (long)be * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
                         *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                        if constexpr (EPI == EPI_RELU) {
-                            if (a.Y2) {    // hd = h + d_0 for the first dilated conv
-                                float dd[4];
-                                f4arr(ed2[mi][q], dd);
-                                const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
-                                if (a.out_s3 & 2) {
-                                    store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
-                                } else {
-                                    float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                                    *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                    }
+                } else {
+    #pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int p0 = mt * 128 + wr * WROWS + mi * 32 + rq;
+                        float v[4], bb[4], o[4];
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * q + e];
+                        f4arr(ebias[mi][q], bb);
+                        if constexpr (EPI == EPI_RES_SKIP) {
+                            float pv[4];
+                            f4arr(eop[mi][ni][q], pv);
+                            // packed rows [0, y_rows) are the residual half, [y_rows, 2*y_rows) the skip half
+                            // (y_rows is a multiple of 64, so the branch is wave-uniform)
+                            if (p0 < a.y_rows) {   // h = (h + (acc + be)) / sqrt(2), in place (:151)
+                                float* dst = a.Y + (long)be * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
+                                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                                if (a.Y2) {        // hd = h + d_{l+1}: the next dilated conv's input (:139)
+                                    float dd[4];
+                                    f4arr(ed2[mi][q], dd);
+                                    const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                                    if (a.out_s3 & 2) {
+                                        store_s3_quad(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                    } else {
+                                        float* dst2 = a.Y2 + (long)be * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                        *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                                    }
+                                }
+                            } else {               // skip (+)= acc + be (:680)
+                                float* dst = a.skip + (long)be * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+    #pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
+                                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                            }
+                        } else {
+                            if (p0 >= a.y_rows) continue;
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if constexpr (EPI == EPI_PLAIN) o[e] = a.alpha * v[e] + bb[e];
+                                else if constexpr (EPI == EPI_RELU) o[e] = fmaxf(a.alpha * v[e] + bb[e], 0.f);
+                                else if constexpr (EPI == EPI_SILU) { const float z = v[e] + bb[e]; o[e] = z * sigmoidf_(z); }
+                                else o[e] = logf(v[e] + 1e-6f);
+                            }
+                            float* dst = a.Y + (long)be * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                            if constexpr (EPI == EPI_RELU) {
+                                if (a.Y2) {    // hd = h + d_0 for the first dilated conv
+                                    float dd[4];
+                                    f4arr(ed2[mi][q], dd);
+                                    const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
+                                    if (a.out_s3 & 2) {
+                                        store_s3_quad(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                    } else {
+                                        float* dst2 = a.Y2 + (long)be * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                                        *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                                    }
                                 }
                             }
                         }
