@@ -460,8 +460,9 @@ def test_roll_longer_than_spectrogram_is_trimmed(full_model):
 
 
 def test_flexible_width_tiles_vs_oracle(monkeypatch):
-    """The 16x16-MFMA flexible-width kernels (96 / 160-frame blocks) are chosen by shape; force each
-    one and hold it to the oracle on a shape that exercises ragged tails and every dilation."""
+    """Kernel flavours are chosen per launch geometry (16x16-MFMA 96 / 160-frame blocks, 32x32-MFMA 64 / 128,
+    the direct-operand 1x1 at 64 .. 160 frames, split-K): force each one and hold it to the oracle on shapes
+    that exercise ragged tails and every dilation."""
     import subprocess, sys, textwrap
     # the tile override is read once per process: run each forced variant in a child process
     code = textwrap.dedent("""
@@ -485,9 +486,12 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
             worst = max(worst, float((out.cpu() - ref).abs().max()), float((step.cpu() - ref_step).abs().max()))
         print("WORST", worst)
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for tile in ("16:3", "16:5", "32:2", "32:1"):
-        env = dict(os.environ, DR_TILE=tile)
+    variants = [{"DR_TILE": t} for t in ("16:3", "16:5", "32:2", "32:1")]
+    # the 1x1 kernel flavours: direct-operand pw_kernel at every block width, the LDS-staged kernel, no split-K
+    variants += [{"DR_PW_NW": n} for n in ("2", "3", "4", "5")] + [{"DR_PW": "0"}, {"DR_KSPLIT_MAX": "1"}]
+    for var in variants:
+        env = dict(os.environ, **var)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, (tile, r.stderr[-2000:])
+        assert r.returncode == 0, (var, r.stderr[-2000:])
         worst = float(r.stdout.strip().split("WORST")[-1])
-        assert worst <= ATOL_FWD, (tile, worst)
+        assert worst <= ATOL_FWD, (var, worst)
