@@ -34,15 +34,14 @@ struct LayerW {
     int dil = 1;
 };
 
+// What a captured chain bakes in: sampler, shape and the buffer addresses.  Seed, batch offset and guidance
+// weight are NOT part of it - they live in the DynParams device block.
 struct GraphKey {
-    int sampler = -1, B = 0, T = 0, first_sample = 0;
+    int sampler = -1, B = 0, T = 0;
     float* x = nullptr;
     const float* noise = nullptr;
-    float w = 0.f;
-    uint64_t seed = 0;
     bool operator==(const GraphKey& o) const {
-        return sampler == o.sampler && B == o.B && T == o.T && first_sample == o.first_sample && x == o.x &&
-               noise == o.noise && w == o.w && seed == o.seed;
+        return sampler == o.sampler && B == o.B && T == o.T && x == o.x && noise == o.noise;
     }
 };
 
@@ -90,6 +89,8 @@ struct dr_engine {
     long long* dbg_ticks = nullptr;     // dr_bench_layer measurement hook
     unsigned long long* d_counts = nullptr;   // dr_frame_counts accumulator
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
+    DynParams* d_dyn = nullptr;         // per-call scalars of the captured chain (seed, batch offset, guidance weight)
+    bool use_dyn = false;               // set while the chain is being captured: run_step points the update at d_dyn
 
     // profiling of the dominant kernel
     bool prof = false;
@@ -471,6 +472,7 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
     u.n = (long)B * T * 88; u.per_sample = (long)T * 88;
     u.w = w; u.onepw = (float)(1.0 + (double)w);
     u.seed = seed; u.first_sample = first_sample;
+    u.dyn = e->use_dyn ? e->d_dyn : nullptr;
     HIPCHK(e, launch_update(u, st));
     return DR_OK;
 }
@@ -557,6 +559,7 @@ void dr_destroy(dr_engine* e) {
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     if (e->d_counts) (void)hipFree(e->d_counts);
+    if (e->d_dyn) (void)hipFree(e->d_dyn);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
@@ -743,6 +746,7 @@ int dr_commit(dr_engine* e, void* stream) {
     if ((rc = dev_alloc(e, &e->d_dtab, (size_t)S * L * Cp))) return rc;
     if ((rc = dev_alloc(e, &e->sk_ws, dr_engine::SK_WS_FLOATS, false))) return rc;
     if ((rc = dev_alloc(e, &e->sk_cnt, dr_engine::SK_CNT_N))) return rc;
+    if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by
         // the same GEMM kernel; result d_dtab[t][l][c].
@@ -897,8 +901,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     if (!use_graph || e->prof) return chain();
 
     GraphKey key;
-    key.sampler = sampler; key.B = B; key.T = T; key.first_sample = first_sample; key.x = d_x; key.noise = d_noise;
-    key.w = w; key.seed = seed;
+    key.sampler = sampler; key.B = B; key.T = T; key.x = d_x; key.noise = d_noise;
     if (!e->gexec || !(key == e->gkey)) {
         if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
@@ -906,7 +909,9 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         hipStream_t user = st;
         st = e->cap_stream;   // chain() launches on `st`
         HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        e->use_dyn = true;
         rc = chain();
+        e->use_dyn = false;
         hipGraph_t gr = nullptr;
         hipError_t ce = hipStreamEndCapture(st, &gr);
         st = user;
@@ -916,6 +921,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->gkey = key;
     }
+    HIPCHK(e, launch_set_dyn(e->d_dyn, seed, first_sample, w, (float)(1.0 + (double)w), st));
     HIPCHK(e, hipGraphLaunch(e->gexec, st));
     return DR_OK;
 }

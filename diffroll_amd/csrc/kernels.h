@@ -90,6 +90,16 @@ hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 
+// Per-call scalars of the update that must not be baked into a captured graph: the chain graph reads them from
+// this device block, which a one-thread kernel rewrites (stream-ordered) before every graph launch - a new
+// seed / batch offset / guidance weight re-uses the instantiated graph.
+struct DynParams {
+    unsigned long long seed;
+    int first_sample;
+    float w, onepw;
+};
+hipError_t launch_set_dyn(DynParams* d, unsigned long long seed, int first_sample, float w, float onepw, hipStream_t s);
+
 struct UpdateArgs {
     float* x;              // (B, T, 88) in/out
     const float* x0c;      // (B, T, 88) conditional (or the only) prediction
@@ -103,6 +113,7 @@ struct UpdateArgs {
     float w, onepw;
     uint64_t seed;
     int first_sample;
+    const DynParams* dyn;  // non-null: w / onepw / seed / first_sample are read from here instead
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
 

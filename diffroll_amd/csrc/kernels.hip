@@ -1378,11 +1378,15 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
     if (i4 * 4 >= a.n) return;
     const float4 xc = reinterpret_cast<const float4*>(a.x0c)[i4];
     float x0[4] = {xc.x, xc.y, xc.z, xc.w};
+    // per-call scalars: by value (eager launches) or from the device block (captured chain)
+    const float gw = a.dyn ? a.dyn->w : a.w, g1pw = a.dyn ? a.dyn->onepw : a.onepw;
+    const uint64_t seed = a.dyn ? a.dyn->seed : a.seed;
+    const int first_sample = a.dyn ? a.dyn->first_sample : a.first_sample;
     if (a.x0u) {
         const float4 xu = reinterpret_cast<const float4*>(a.x0u)[i4];
         const float u[4] = {xu.x, xu.y, xu.z, xu.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x0[e] = a.onepw * x0[e] - a.w * u[e];
+        for (int e = 0; e < 4; ++e) x0[e] = g1pw * x0[e] - gw * u[e];
     }
     const float c0 = a.coef[0], c1 = a.coef[1], c2 = a.coef[2], c3 = a.coef[3], c4 = a.coef[4];
     float o[4];
@@ -1403,7 +1407,7 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
             const long within = (e0 - smp * a.per_sample) >> 2;
             uint32_t rnd[4];
             philox4x32_10((uint32_t)within, (uint32_t)(within >> 32), (uint32_t)a.t,
-                          (uint32_t)(a.first_sample + smp), (uint32_t)a.seed, (uint32_t)(a.seed >> 32), rnd);
+                          (uint32_t)(first_sample + smp), (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
             box_muller(rnd[0], rnd[1], z[0], z[1]);
             box_muller(rnd[2], rnd[3], z[2], z[3]);
         }
@@ -1432,6 +1436,14 @@ __global__ __launch_bounds__(256) void update_kernel(const UpdateArgs a) {
         }
     }
     reinterpret_cast<float4*>(a.x)[i4] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ void set_dyn_kernel(DynParams* d, unsigned long long seed, int first_sample, float w, float onepw) {
+    d->seed = seed; d->first_sample = first_sample; d->w = w; d->onepw = onepw;
+}
+hipError_t launch_set_dyn(DynParams* d, unsigned long long seed, int first_sample, float w, float onepw, hipStream_t s) {
+    hipLaunchKernelGGL(set_dyn_kernel, dim3(1), dim3(1), 0, s, d, seed, first_sample, w, onepw);
+    return hipGetLastError();
 }
 
 hipError_t launch_update(const UpdateArgs& a, hipStream_t s) {
