@@ -34,8 +34,9 @@ struct LayerW {
     int dil = 1;
 };
 
-// What a captured chain bakes in: sampler, shape and the buffer addresses.  Seed, batch offset and guidance
-// weight are NOT part of it - they live in the DynParams device block.
+// What a captured chain bakes in: sampler, shape, the engine's work buffer and the injected-noise address (test
+// mode).  Seed, batch offset and guidance weight live in the DynParams device block; the caller's roll buffer
+// is copied into / out of the work buffer around the launch.
 struct GraphKey {
     int sampler = -1, B = 0, T = 0;
     float* x = nullptr;
@@ -71,6 +72,7 @@ struct dr_engine {
     float* sk_cnt = nullptr;
     static constexpr size_t SK_WS_FLOATS = (size_t)8 << 20, SK_CNT_N = 4096;
     float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
+    float* xwork = nullptr;                // the captured chain runs in place on this engine-owned roll buffer
     float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
     int prec = 0;                          // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3, 6 products)
     // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
@@ -349,6 +351,7 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     if ((rc = dev_alloc(e, &e->skip, act))) return rc;
     if ((rc = dev_alloc(e, &e->tmp, act))) return rc;
     if ((rc = dev_alloc(e, &e->x0buf, (size_t)nb * T * 88))) return rc;
+    if ((rc = dev_alloc(e, &e->xwork, (size_t)nb * T * 88))) return rc;
     if ((rc = dev_alloc(e, &e->cond_dummy, (size_t)2 * e->Cp * T))) return rc;
     e->ws_NB = nb;
     e->ws_T = T;
@@ -563,7 +566,7 @@ void dr_destroy(dr_engine* e) {
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
-                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt};
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt, e->xwork};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -889,19 +892,19 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     if ((rc = ensure_workspace(e, NB, T))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const size_t per = (size_t)B * T * 88;
-    auto chain = [&]() -> int {
+    auto chain = [&](float* xbuf) -> int {
         for (int t = e->S - 1; t >= 0; --t) {
             // row t of the injected noise is the z of step t; t == 0 draws none (task/diffusion.py:957-960)
             const float* z = d_noise ? d_noise + (size_t)t * per : nullptr;
-            int r = run_step(e, sampler, d_x, z, B, T, t, w, seed, first_sample, st);
+            int r = run_step(e, sampler, xbuf, z, B, T, t, w, seed, first_sample, st);
             if (r) return r;
         }
         return DR_OK;
     };
-    if (!use_graph || e->prof) return chain();
+    if (!use_graph || e->prof) return chain(d_x);
 
     GraphKey key;
-    key.sampler = sampler; key.B = B; key.T = T; key.x = d_x; key.noise = d_noise;
+    key.sampler = sampler; key.B = B; key.T = T; key.x = e->xwork; key.noise = d_noise;
     if (!e->gexec || !(key == e->gkey)) {
         if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
@@ -910,7 +913,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         st = e->cap_stream;   // chain() launches on `st`
         HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         e->use_dyn = true;
-        rc = chain();
+        rc = chain(e->xwork);
         e->use_dyn = false;
         hipGraph_t gr = nullptr;
         hipError_t ce = hipStreamEndCapture(st, &gr);
@@ -921,8 +924,11 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->gkey = key;
     }
+    // the graph owns no caller address: x_T is copied in, the finished roll copied out (0.7 MB each way)
+    HIPCHK(e, hipMemcpyAsync(e->xwork, d_x, per * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(e, launch_set_dyn(e->d_dyn, seed, first_sample, w, (float)(1.0 + (double)w), st));
     HIPCHK(e, hipGraphLaunch(e->gexec, st));
+    HIPCHK(e, hipMemcpyAsync(d_x, e->xwork, per * sizeof(float), hipMemcpyDeviceToDevice, st));
     return DR_OK;
 }
 

@@ -158,7 +158,6 @@ class ClassifierFreeDiffRoll(nn.Module):
         self._dirty = True
         self._fe_key = None
         self._fe_spec = None
-        self._xbuf = {}
         self.reverse_diffusion = getattr(self, sampling.type)                  # task/diffusion.py:255
 
     # ------------------------------------------------------------------ plumbing
@@ -328,12 +327,9 @@ class ClassifierFreeDiffRoll(nn.Module):
         else:
             Tm = T if waveform is None else min(T, waveform.shape[-1] // eng.hop_length + 1)
             spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
-        # the chain runs in place on an engine-lifetime buffer so that the captured hipGraph (which
-        # bakes device pointers) is replayed, not re-captured, when the same shape comes again
-        xb = self._xbuf.get((B, Tm))
-        if xb is None:
-            xb = self._xbuf[(B, Tm)] = torch.empty(B, Tm, 88, device=eng.device, dtype=torch.float32)
-        xb.copy_(x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :])
+        # a fresh roll buffer per call: the engine's captured chain runs on its own work buffer, so caller
+        # addresses never force a re-capture
+        xb = x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].clone(memory_format=torch.contiguous_format)
         z = None
         if noise is not None:
             S = self.hparams.timesteps
@@ -342,7 +338,7 @@ class ClassifierFreeDiffRoll(nn.Module):
                 z = z[:, :, :Tm, :].contiguous()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         eng.sample(sampler, xb, z, w, seed, first_sample, use_graph)
-        return xb.clone().unsqueeze(1), spec
+        return xb.unsqueeze(1), spec
 
     def predict_step(self, batch, batch_idx=0):
         """batch = (x_T, waveform[, ...]) as built by sampling.py:27-46.  Returns the final roll

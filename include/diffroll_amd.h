@@ -172,8 +172,8 @@ int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, 
  * The whole reverse chain t = timesteps-1 .. 0, in place on d_x, no host synchronisation.
  * d_noise: (timesteps, B, T, 88) injected noise (row t used at step t >= 1) or NULL for Philox.
  * use_graph != 0: the chain is captured once into a hipGraph and replayed; the graph is cached per
- * (sampler, B, T, d_x, d_noise) - w, seed and first_sample are read from a device block at run time, so
- * new values re-use the instantiated graph.  Needs dr_frontend first unless sampler == DR_SAMPLER_GENERATION_DDPM_X0.
+ * (sampler, B, T, d_noise): the chain runs on an engine-owned copy of d_x, and w, seed and first_sample are
+ * read from a device block at run time, so new buffers / values re-use the instantiated graph.  Needs dr_frontend first unless sampler == DR_SAMPLER_GENERATION_DDPM_X0.
  */
 int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T,
               float w, uint64_t seed, int first_sample, int use_graph, void* stream);
