@@ -190,6 +190,47 @@ def test_config1_chain_vs_oracle():
     assert bool((((roll > 0.5) == (ref > 0.5)) | near).all())
 
 
+def test_config5_shape_step_vs_oracle():
+    """BASELINE config 5 geometry - k=15, 640-frame segments, 4 clips per GPU - full width and depth: one
+    classifier-free-guidance step (2 x 4 evaluations: 160-frame conv blocks, 160-frame 1x1 blocks, the shared
+    first-layer contraction) against the oracle with injected noise."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(kernel_size=15, timesteps=200)
+    p = R.synthetic_params(hp, seed=15)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    torch.manual_seed(5)
+    B, Tn = 4, 640
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(B, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], 200)
+    with torch.no_grad():
+        spec = R.frontend(wav, hp, Tn)
+        ref = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, spec, 150, z, 0.5)
+    out, _ = m.reverse_diffusion(x, wav, 150, noise=z)
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
+def test_config3_generation_steps_vs_oracle(full_model):
+    """BASELINE config 3 per-GPU geometry: unconditional generation (spec == -1), 16 clips of 125 frames - three
+    consecutive reverse steps (one evaluation each, 64-frame blocks) against the oracle."""
+    hp, p, _ = full_model
+    m = make_model(hp, p, sampler="generation_ddpm_x0", w=0.0)
+    torch.manual_seed(3)
+    B, Tn = 16, 125
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(3, B, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    spec = torch.full((B, hp["n_mels"], Tn), -1.0)
+    ref, out = x, x
+    with torch.no_grad():
+        for i, t in enumerate((120, 119, 118)):
+            ref = R.reverse_step(p, hp, sch, "generation_ddpm_x0", ref, spec, t, z[i], 0.0)
+    for i, t in enumerate((120, 119, 118)):
+        out, _ = m.reverse_diffusion(out, None, t, noise=z[i])
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
 # --------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE config 2 shape (B=16, T=125, k=9, 200 steps)
 # --------------------------------------------------------------------------------------------
