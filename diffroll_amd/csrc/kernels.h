@@ -79,7 +79,8 @@ struct GemmArgs {
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
 };
 
-// NI = N sub-tiles of 32 frames per wave: block tile = 128 rows x (64*NI) frames, 256 threads.
+// gemm_kernel: block tile = 128 packed rows x 64*NI frames (NI in {1, 2}), 512 threads (4 consumer + 4 producer
+// waves); call init_kernels() once per process before any launch.
 hipError_t init_kernels();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);

@@ -145,9 +145,10 @@ DR_DEVINL float gatef_(float u, float v) {
 //
 //   A operand (weights): NEVER staged through LDS.  The packed layout is fragment-shaped, so every
 //   consumer wave loads the 4 float4 A-fragments of a K step (4 channel groups x its 32 rows) straight
-//   from L2 into VGPRs with two fully coalesced 512-B segments per instruction, one step ahead of use
-//   (measured free).  The 128-row weight panel of an M tile is L2-resident: blockIdx % MT pins a
-//   panel to an XCD.
+//   from L2 into VGPRs - buffer loads off the M tile's weight panel (resource in SGPRs, fixed per-lane
+//   offset, scalar per-step offset: no vector address arithmetic), two fully coalesced 512-B segments per
+//   instruction, one step ahead of use, spread through the first group's MFMAs.  The 128-row weight panel
+//   of an M tile is L2-resident: blockIdx % MT pins a panel to an XCD.
 //   B operand (activations): X tile [KS*8 planes][FW = BN + 2*halo frames][float4] in LDS; all taps of
 //   the dilated conv read it at shifted frame offsets with conflict-free ds_read_b128.
 //   K loop: for chunk (32*KS input channels) for tap for sub-chunk: 64*NI MFMAs per consumer wave.
