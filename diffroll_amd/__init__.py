@@ -8,5 +8,7 @@ behind a C-ABI (include/diffroll_amd.h), exposed through the reference's own Pyt
 """
 from .model import ClassifierFreeDiffRoll, AttrDict      # noqa: F401
 from .engine import Engine, EngineError                    # noqa: F401
+from .diffusion import q_sample, extract_x0, linear_beta_schedule   # noqa: F401
 
-__all__ = ["ClassifierFreeDiffRoll", "Engine", "EngineError", "AttrDict"]
+__all__ = ["ClassifierFreeDiffRoll", "Engine", "EngineError", "AttrDict", "q_sample", "extract_x0",
+           "linear_beta_schedule"]

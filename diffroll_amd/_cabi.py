@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 2
+DR_ABI_VERSION = 3
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
 
 SAMPLERS = {
@@ -31,7 +31,8 @@ PRECISIONS = {"f32": 0, "bf16x3": 1}
 # every symbol include/diffroll_amd.h declares
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
-    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_set_precision", "dr_profile_enable",
+    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
+    "dr_extract_x0", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
 ]
 
@@ -87,6 +88,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_frame_counts.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_int64), vp]
     lib.dr_note_runs.restype = C.c_int
     lib.dr_note_runs.argtypes = [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp]
+    for fn in (lib.dr_q_sample, lib.dr_extract_x0):
+        fn.restype = C.c_int
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp]
     lib.dr_set_precision.restype = C.c_int
     lib.dr_set_precision.argtypes = [vp, C.c_int]
     lib.dr_profile_enable.restype = C.c_int

@@ -959,6 +959,24 @@ int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, siz
     return DR_OK;
 }
 
+static int noise_mix(dr_engine* e, int mode, const float* a, const float* b, const int64_t* d_t, const float* d_sac,
+                     const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out, void* stream) {
+    // e may be NULL (free functions of the reference: no engine state is involved; current device; the error text
+    // is then read with dr_last_error(NULL))
+    if (!a || !b || !d_t || !d_sac || !d_s1m || !d_out) return fail(e, DR_EINVAL, "null argument");
+    if (B <= 0 || n_steps <= 0 || per_sample == 0) return fail(e, DR_EINVAL, "bad shape B=%d n_steps=%d", B, n_steps);
+    HIPCHK(e, launch_noise_mix(mode, a, b, d_t, d_sac, d_s1m, n_steps, B, (long)per_sample, d_out, (hipStream_t)stream));
+    return DR_OK;
+}
+int dr_q_sample(dr_engine* e, const float* d_x_start, const float* d_noise, const int64_t* d_t, const float* d_sac,
+                const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out, void* stream) {
+    return noise_mix(e, 0, d_x_start, d_noise, d_t, d_sac, d_s1m, n_steps, B, per_sample, d_out, stream);
+}
+int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, const int64_t* d_t, const float* d_sac,
+                  const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out, void* stream) {
+    return noise_mix(e, 1, d_x_t, d_epsilon, d_t, d_sac, d_s1m, n_steps, B, per_sample, d_out, stream);
+}
+
 int dr_profile_enable(dr_engine* e, int on) {
     if (!e) return DR_EINVAL;
     HIPCHK(e, hipSetDevice(e->cfg.device));

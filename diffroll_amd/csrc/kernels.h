@@ -126,6 +126,9 @@ hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4,
                             int B, int planes_in, int planes_out, int TF, int T, int n_rows,
                             int mt0, int mt1, int mf0, int mf1, hipStream_t s);
 hipError_t launch_fill(float* p, float v, long n, hipStream_t s);
+// q_sample / extract_x0 of task/diffusion.py:31-64 (mode 0 / 1): per-sample schedule lookup by t[b], elementwise
+hipError_t launch_noise_mix(int mode, const float* x, const float* y, const int64_t* t, const float* sac,
+                            const float* s1m, int n_steps, int B, long per_sample, float* out, hipStream_t s);
 // note_end[b][t][p] = offset frame (exclusive) of the note that STARTS at frame t on pitch p, else 0:
 // roll (B, T, 88) thresholded at thr; a note = maximal run of frames above the threshold (rule1 with
 // onsets == frames, task/diffusion.py:1185-1233)

@@ -1566,6 +1566,33 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// q_sample (mode 0, task/diffusion.py:31-46): out = sac[t] * x + s1m[t] * y;  extract_x0 (mode 1, :49-64):
+// out = (x - s1m[t] * y) / sac[t], t per sample.  HBM-bound (12 B per element); each operation rounds once, in
+// the reference's order (contraction off, IEEE division), so results are bit-identical to the torch expression.
+__global__ __launch_bounds__(256) void noise_mix_kernel(int mode, const float* __restrict__ x, const float* __restrict__ y,
+                                                        const int64_t* __restrict__ t, const float* __restrict__ sac,
+                                                        const float* __restrict__ s1m, int n_steps, long per_sample,
+                                                        float* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.y;
+    long ti = t[b];
+    ti = ti < 0 ? 0 : (ti >= n_steps ? n_steps - 1 : ti);
+    const float a = sac[ti], c = s1m[ti];
+    const long base = (long)b * per_sample;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (long)gridDim.x * 256) {
+        const float xv = x[base + i], yv = y[base + i];
+        out[base + i] = mode == 0 ? (a * xv) + (c * yv) : (xv - c * yv) / a;
+    }
+}
+hipError_t launch_noise_mix(int mode, const float* x, const float* y, const int64_t* t, const float* sac,
+                            const float* s1m, int n_steps, int B, long per_sample, float* out, hipStream_t s) {
+    if (B <= 0 || per_sample <= 0) return hipSuccess;
+    const long bx = (per_sample + 255) / 256;
+    hipLaunchKernelGGL(noise_mix_kernel, dim3((unsigned)(bx < 1024 ? bx : 1024), (unsigned)B), dim3(256), 0, s, mode, x, y, t,
+                       sac, s1m, n_steps, per_sample, out);
+    return hipGetLastError();
+}
+
 // Roll -> note runs (task/diffusion.py:1185-1233 with onsets == frames, rule1): one thread per
 // (sample, pitch) column walks the T frames once, backwards, so every note start learns its offset in
 // O(T) total; lanes of a wave cover 64 consecutive pitches of a frame (coalesced 256-B reads).  Index

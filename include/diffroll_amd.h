@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 2
+#define DR_ABI_VERSION 3
 
 enum {
     DR_OK = 0,
@@ -195,6 +195,22 @@ int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshol
  */
 int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, size_t n, float threshold,
                     int64_t* host_counts, void* stream);
+
+/*
+ * The forward-process arithmetic of task/diffusion.py (free functions, used by step() around the network):
+ *   dr_q_sample   (:31-46)  out = sqrt_alphas_cumprod[t_b] * x_start + sqrt_one_minus_alphas_cumprod[t_b] * noise
+ *   dr_extract_x0 (:49-64)  out = (x_t - sqrt_one_minus_alphas_cumprod[t_b] * epsilon) / sqrt_alphas_cumprod[t_b]
+ * d_t (B,) int64 per-sample step indices, d_sac / d_s1m the two schedule vectors (n_steps,) - all on the
+ * device; tensors are (B, per_sample) contiguous fp32.  Same operation order and roundings as the reference's
+ * broadcasted torch expression (bit-exact).  Step indices are clamped to [0, n_steps).  `e` may be NULL (no
+ * engine state is involved: current device, error text via dr_last_error(NULL)).
+ */
+int dr_q_sample(dr_engine* e, const float* d_x_start, const float* d_noise, const int64_t* d_t,
+                const float* d_sac, const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out,
+                void* stream);
+int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, const int64_t* d_t,
+                  const float* d_sac, const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out,
+                  void* stream);
 
 /* Select DR_PRECISION_* for subsequent dr_forward / dr_step / dr_sample calls (default F32).
  * Drops a captured chain. */

@@ -256,6 +256,22 @@ def forward(params: Dict[str, Tensor], hp: dict, x_t: Tensor, waveform: Tensor, 
 # --------------------------------------------------------------------------
 # samplers  (task/diffusion.py:831-853, :943-1025)
 # --------------------------------------------------------------------------
+def q_sample(x_start: Tensor, t: Tensor, sqrt_alphas_cumprod: Tensor, sqrt_one_minus_alphas_cumprod: Tensor,
+             noise: Tensor) -> Tensor:
+    """task/diffusion.py:31-46: forward process, per-sample step index t (B,) broadcast over (B,1,T,F)."""
+    a = sqrt_alphas_cumprod[t][:, None, None, None]
+    c = sqrt_one_minus_alphas_cumprod[t][:, None, None, None]
+    return a * x_start + c * noise
+
+
+def extract_x0(x_t: Tensor, epsilon: Tensor, t: Tensor, sqrt_alphas_cumprod: Tensor,
+               sqrt_one_minus_alphas_cumprod: Tensor) -> Tensor:
+    """task/diffusion.py:49-64: x_0 from x_t and the predicted noise (inverse of eq. 4 of DDPM)."""
+    a = sqrt_alphas_cumprod[t][:, None, None, None]
+    c = sqrt_one_minus_alphas_cumprod[t][:, None, None, None]
+    return (x_t - c * epsilon) / a
+
+
 def posterior_update(sch: Dict[str, Tensor], x: Tensor, x0_pred: Tensor, t_index: int,
                      z: Optional[Tensor]) -> Tensor:
     """task/diffusion.py:957-967 (identical in all *_ddpm_x0 samplers)."""

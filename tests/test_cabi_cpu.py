@@ -21,7 +21,7 @@ def lib():
 def header_functions():
     text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dr_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(dr_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree(lib):

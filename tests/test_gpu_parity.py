@@ -483,6 +483,28 @@ def test_ragged_shapes_vs_oracle(k, precision):
         assert d <= ATOL_STEP, (B, Tn, d)
 
 
+def test_q_sample_extract_x0_bit_exact(golden_dir):
+    """diffroll_amd.q_sample / extract_x0 (dr_q_sample / dr_extract_x0) against the reference's free functions'
+    outputs (task/diffusion.py:31-64): same operation order, one rounding per operation -> bit-exact; also
+    against the oracle on a larger ragged case."""
+    import diffroll_amd as D
+    g = np.load(os.path.join(golden_dir, "qsample.npz"))
+    dev = torch.device("cuda", 0)
+    xt = D.q_sample(T(g["x0"]).to(dev), T(g["t"]), T(g["sac"]), T(g["s1m"]), noise=T(g["noise"]).to(dev))
+    assert xt.shape == tuple(g["xt"].shape) and torch.equal(xt.cpu(), T(g["xt"]))
+    x0b = D.extract_x0(T(g["xt"]).to(dev), T(g["eps"]).to(dev), T(g["t"]), T(g["sac"]), T(g["s1m"]))
+    assert torch.equal(x0b.cpu(), T(g["x0_back"]))
+    torch.manual_seed(9)
+    sch = R.schedule(1e-4, 0.02, 50)
+    x0, nz = torch.rand(7, 1, 333, 88), torch.randn(7, 1, 333, 88)
+    t = torch.randint(0, 50, (7,))
+    ref = R.q_sample(x0, t, sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"], nz)
+    out = D.q_sample(x0.to(dev), t, sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"], noise=nz.to(dev))
+    assert torch.equal(out.cpu(), ref)
+    with pytest.raises(TypeError):
+        D.q_sample(x0.to(dev), t, sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"])
+
+
 def test_roll_longer_than_spectrogram_is_trimmed(full_model):
     """trim_spec_roll (model/diffwave.py:30-39): T_roll > L // hop + 1 -> outputs have T' = L // hop + 1 frames."""
     hp = dict(R.DEFAULT_HP)

@@ -120,3 +120,13 @@ def test_note_extraction_matches_reference(golden_dir):
             p_, i_ = R.extract_notes_wo_velocity(g[f"roll{i}"], g[f"roll{i}"], thr, thr)
             assert np.array_equal(np.asarray(p_, dtype=np.int64), g[f"pitches{i}_{thr}"])
             assert np.array_equal(np.asarray(i_, dtype=np.int64).reshape(-1, 2), g[f"intervals{i}_{thr}"])
+
+
+def test_q_sample_extract_x0_bit_exact(golden_dir):
+    """oracle q_sample / extract_x0 == the reference's free functions (task/diffusion.py:31-64), bit for bit."""
+    g = np.load(os.path.join(golden_dir, "qsample.npz"))
+    T_ = lambda k: torch.from_numpy(np.asarray(g[k]))
+    xt = R.q_sample(T_("x0"), T_("t"), T_("sac"), T_("s1m"), T_("noise"))
+    assert torch.equal(xt, T_("xt"))
+    x0b = R.extract_x0(T_("xt"), T_("eps"), T_("t"), T_("sac"), T_("s1m"))
+    assert torch.equal(x0b, T_("x0_back"))
