@@ -360,15 +360,26 @@ class ClassifierFreeDiffRoll(nn.Module):
         """Frame-level part of task/diffusion.py:312-428: sample the batch, threshold the final roll at
         hparams.frame_threshold and score it against batch['frame'] exactly as
         sklearn.metrics.precision_recall_fscore_support(label.flatten(), pred.flatten() > thr,
-        average='binary') does (:381-383).  Returns the metrics the reference logs per batch
-        (note-level F1 via mir_eval is host-side post-processing and out of scope)."""
+        average='binary') does (:381-383); then the note-level score of :385-410 - notes extracted from the
+        prediction and from the label roll (GPU run-length scan), onset-only matching as mir_eval's
+        precision_recall_f1_overlap(offset_ratio=None) (diffroll_amd/metrics.py; parity unpinned: mir_eval is
+        absent here).  Returns the metrics the reference logs; Test/Note_F1 is the mean over the batch (the
+        reference logs it for the samples of batch 0 only, :426)."""
+        from . import midi, metrics
         roll, _ = self.sampling(batch, batch_idx)
         label = batch["frame"]
         Tm = roll.shape[2]
-        tp, fp, fn = self.engine.frame_counts(roll[:, 0], label[:, :Tm].to(roll.device, torch.float32),
-                                              float(self.hparams.frame_threshold))
+        label_dev = label[:, :Tm].to(roll.device, torch.float32).contiguous()
+        thr = float(self.hparams.frame_threshold)
+        tp, fp, fn = self.engine.frame_counts(roll[:, 0], label_dev, thr)
         p, r, f = self.frame_metrics(tp, fp, fn)
-        return {"Test/Frame_F1": f, "Test/Frame_precision": p, "Test/Frame_recall": r, "tp": tp, "fp": fp, "fn": fn}
+        sa = self.hparams.spec_args
+        est = midi.extract_notes_wo_velocity(self.engine, roll, thr)
+        ref = midi.extract_notes_wo_velocity(self.engine, label_dev, thr)
+        notes = metrics.note_scores(ref, est, int(sa.get("hop_length", 512)), int(sa.get("sample_rate", 16000)))
+        note_f1 = float(sum(n[2] for n in notes) / max(len(notes), 1))
+        return {"Test/Frame_F1": f, "Test/Frame_precision": p, "Test/Frame_recall": r, "tp": tp, "fp": fp, "fn": fn,
+                "Test/Note_F1": note_f1, "note_scores": notes}
 
     def export_midi(self, roll, path_prefix="raw_midi_", threshold=0.5):
         """Post-processing of predict_step (task/diffusion.py:598-618): threshold the final roll (the

@@ -362,6 +362,18 @@ def test_frame_f1_matches_sklearn(full_model):
     wav = 0.1 * torch.randn(2, 64000)
     out = m2.test_step({"frame": label[:2], "audio": wav}, 0)
     assert 0.0 <= out["Test/Frame_F1"] <= 1.0 and out["tp"] + out["fn"] == int(label[:2].sum())
+    assert 0.0 <= out["Test/Note_F1"] <= 1.0 and len(out["note_scores"]) == 2
+    # note-level score (task/diffusion.py:385-410): a prediction equal to the label scores 1, one shifted by a
+    # frame (32 ms <= the 50 ms onset tolerance) still 1, shifted by two frames 0
+    from diffroll_amd import midi, metrics
+    lab = torch.zeros(1, Tn, 88)
+    lab[0, 10:20, 40] = 1.0
+    lab[0, 30:33, 52] = 1.0
+    lab[0, 60:90, 12] = 1.0
+    ref = midi.extract_notes_wo_velocity(m.engine, lab.cuda(), 0.5)
+    for shift, want in ((0, 1.0), (1, 1.0), (2, 0.0)):
+        est = midi.extract_notes_wo_velocity(m.engine, torch.roll(lab, shift, dims=1).cuda(), 0.5)
+        assert metrics.note_scores(ref, est, 512, 16000)[0][2] == want
 
 
 # --------------------------------------------------------------------------------------------

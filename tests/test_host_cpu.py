@@ -247,3 +247,48 @@ def test_checkpoint_with_omegaconf_shaped_hparams_loads_without_omegaconf(tmp_pa
     assert m2.hparams.kernel_size == 9 and m2.hparams.spec_args.n_fft == 2048
     for k, v in m.state_dict().items():
         assert torch.equal(m2.state_dict()[k], v)
+
+
+def test_note_metrics_against_exhaustive_matching():
+    """diffroll_amd.metrics (onset-only note matching of mir_eval's precision_recall_f1_overlap, restated:
+    mir_eval is absent) against an exhaustive maximum-matching search on small random cases, plus known answers."""
+    import itertools
+    from diffroll_amd import metrics as M
+    rng = np.random.default_rng(3)
+
+    def brute(ref_i, ref_p, est_i, est_p):
+        hit = [[abs(round(abs(ref_i[a][0] - est_i[b][0]), 6)) <= 0.05 and abs(1200 * np.log2(ref_p[a] / est_p[b])) <= 50
+                for b in range(len(est_p))] for a in range(len(ref_p))]
+        best = 0
+        n_ref, n_est = len(ref_p), len(est_p)
+        for k in range(min(n_ref, n_est), 0, -1):
+            for refs in itertools.combinations(range(n_ref), k):
+                for ests in itertools.permutations(range(n_est), k):
+                    if all(hit[a][b] for a, b in zip(refs, ests)):
+                        return k
+        return best
+
+    for _ in range(60):
+        n_ref, n_est = rng.integers(1, 6), rng.integers(1, 6)
+        ref_on = np.round(rng.integers(0, 12, n_ref) * 0.032, 6)
+        est_on = np.round(rng.integers(0, 12, n_est) * 0.032, 6)
+        ref_i = np.stack([ref_on, ref_on + 0.064], 1)
+        est_i = np.stack([est_on, est_on + 0.064], 1)
+        ref_p = M.midi_to_hz(21 + rng.integers(40, 43, n_ref))
+        est_p = M.midi_to_hz(21 + rng.integers(40, 43, n_est))
+        m = brute(ref_i, ref_p, est_i, est_p)
+        p, r, f = M.evaluate_notes(ref_i, ref_p, est_i, est_p)
+        assert abs(p - m / n_est) < 1e-12 and abs(r - m / n_ref) < 1e-12
+        assert abs(f - (0.0 if m == 0 else 2 * p * r / (p + r))) < 1e-12
+    # known answers: identical notes -> 1; one frame (32 ms) late still matches, two frames (64 ms) do not;
+    # a semitone off never matches; empty estimate -> 0
+    i = np.array([[0.0, 0.5], [1.0, 1.5]])
+    hz = M.midi_to_hz(np.array([60, 64]))
+    assert M.evaluate_notes(i, hz, i, hz) == (1.0, 1.0, 1.0)
+    assert M.evaluate_notes(i, hz, i + 0.032, hz) == (1.0, 1.0, 1.0)
+    assert M.evaluate_notes(i, hz, i + 0.064, hz) == (0.0, 0.0, 0.0)
+    assert M.evaluate_notes(i, hz, i, M.midi_to_hz(np.array([61, 65]))) == (0.0, 0.0, 0.0)
+    assert M.evaluate_notes(i, hz, np.zeros((0, 2)), np.zeros(0)) == (0.0, 0.0, 0.0)
+    # two estimates competing for one reference note: only one can be matched
+    p, r, f = M.evaluate_notes(i[:1], hz[:1], np.array([[0.0, 0.4], [0.032, 0.4]]), hz[[0, 0]])
+    assert (p, r) == (0.5, 1.0)
