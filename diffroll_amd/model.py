@@ -103,7 +103,8 @@ class ClassifierFreeDiffRoll(nn.Module):
                  debug=False,
                  generation_filter=0.0,
                  device=None,
-                 precision="f32"):
+                 precision="f32",
+                 beta_schedule="linear"):
         super().__init__()
         if condition not in ("fixed",):
             if condition in ("trainable_spec", "trainable_z"):
@@ -125,7 +126,9 @@ class ClassifierFreeDiffRoll(nn.Module):
             inpainting_f=inpainting_f, lr=lr, timesteps=timesteps, loss_type=loss_type,
             loss_keys=list(loss_keys), beta_start=beta_start, beta_end=beta_end,
             frame_threshold=frame_threshold, training=training, sampling=sampling, debug=debug,
-            generation_filter=generation_filter)
+            generation_filter=generation_filter, beta_schedule=beta_schedule)
+        if beta_schedule not in ("linear", "cosine", "quadratic", "sigmoid"):
+            raise ValueError(f"unknown beta_schedule '{beta_schedule}'")
         self.spec_dropout = spec_dropout
 
         # parameter containers, same names/shapes/initialisation as the reference
@@ -161,10 +164,20 @@ class ClassifierFreeDiffRoll(nn.Module):
         self.reverse_diffusion = getattr(self, sampling.type)                  # task/diffusion.py:255
 
     # ------------------------------------------------------------------ plumbing
+    def _betas(self):
+        """None for the reference's linear schedule (task/diffusion.py:239), else one of the model/unet.py:558-579
+        schedules (an extension: `beta_schedule=` is not a reference kwarg)."""
+        from . import schedule as S
+        kind = self.__dict__["hparams"].get("beta_schedule", "linear")
+        if kind == "linear":
+            return None
+        return {"cosine": S.cosine_beta_schedule, "quadratic": S.quadratic_beta_schedule,
+                "sigmoid": S.sigmoid_beta_schedule}[kind](self.__dict__["hparams"].timesteps)
+
     @property
     def engine(self) -> Engine:
         if self._engine is None:
-            self._engine = Engine(device=self._device, **self._engine_kwargs)
+            self._engine = Engine(device=self._device, betas=self._betas(), **self._engine_kwargs)
             self._dirty = True
         if self._dirty:
             self._engine.load_params({k: v for k, v in self.state_dict().items()})
@@ -180,7 +193,7 @@ class ClassifierFreeDiffRoll(nn.Module):
                     "sqrt_one_minus_alphas_cumprod", "posterior_variance"):
             from .schedule import make_schedule
             hp = self.__dict__["hparams"]
-            return make_schedule(hp.beta_start, hp.beta_end, hp.timesteps)[name]
+            return make_schedule(hp.beta_start, hp.beta_end, hp.timesteps, self._betas())[name]
         return super().__getattr__(name)
 
     def load_state_dict(self, state_dict, strict: bool = True):

@@ -19,9 +19,36 @@ def linear_beta_schedule(beta_start: float, beta_end: float, timesteps: int) -> 
     return torch.linspace(beta_start, beta_end, timesteps)
 
 
-def make_schedule(beta_start: float, beta_end: float, timesteps: int) -> Dict[str, torch.Tensor]:
-    """The six schedule vectors of SpecRollDiffusion.__init__ (task/diffusion.py:239-256)."""
-    betas = linear_beta_schedule(beta_start, beta_end, timesteps)
+def cosine_beta_schedule(timesteps, s=0.008):
+    """model/unet.py:558-567 (https://arxiv.org/abs/2102.09672), same torch expressions."""
+    steps = timesteps + 1
+    x = torch.linspace(0, timesteps, steps)
+    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0.0001, 0.9999)
+
+
+def quadratic_beta_schedule(timesteps):
+    """model/unet.py:570-573."""
+    beta_start = 0.0001
+    beta_end = 0.02
+    return torch.linspace(beta_start**0.5, beta_end**0.5, timesteps) ** 2
+
+
+def sigmoid_beta_schedule(timesteps):
+    """model/unet.py:575-579."""
+    beta_start = 0.0001
+    beta_end = 0.02
+    betas = torch.linspace(-6, 6, timesteps)
+    return torch.sigmoid(betas) * (beta_end - beta_start) + beta_start
+
+
+def make_schedule(beta_start: float, beta_end: float, timesteps: int, betas: torch.Tensor = None) -> Dict[str, torch.Tensor]:
+    """The six schedule vectors of SpecRollDiffusion.__init__ (task/diffusion.py:239-256).  `betas` replaces the
+    linear schedule (e.g. one of the model/unet.py schedules above): everything downstream - the coefficient
+    tables the engine reads - only sees these vectors."""
+    betas = linear_beta_schedule(beta_start, beta_end, timesteps) if betas is None else betas.to(torch.float32)
     alphas = 1. - betas
     alphas_cumprod = torch.cumprod(alphas, axis=0)
     alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.0)

@@ -86,8 +86,9 @@ def conv_padding(kernel_size: int, dilation: int) -> int:
 # --------------------------------------------------------------------------
 # noise schedule  (task/diffusion.py:239-256)
 # --------------------------------------------------------------------------
-def schedule(beta_start: float, beta_end: float, timesteps: int) -> Dict[str, Tensor]:
-    betas = torch.linspace(beta_start, beta_end, timesteps)  # :28-29
+def schedule(beta_start: float, beta_end: float, timesteps: int, betas: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    if betas is None:
+        betas = torch.linspace(beta_start, beta_end, timesteps)  # :28-29
     alphas = 1.0 - betas
     alphas_cumprod = torch.cumprod(alphas, axis=0)
     alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.0)

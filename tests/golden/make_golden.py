@@ -197,6 +197,19 @@ def gen_notes():
     save("notes", n=len(rolls), **out)
 
 
+def gen_beta_schedules():
+    """The extra beta schedules of model/unet.py:558-579, run from the reference."""
+    RI.import_reference_model()
+    import importlib
+    U = importlib.import_module("model.unet")
+    out = {}
+    for S in (50, 200):
+        out[f"cosine_{S}"] = U.cosine_beta_schedule(S)
+        out[f"quadratic_{S}"] = U.quadratic_beta_schedule(S)
+        out[f"sigmoid_{S}"] = U.sigmoid_beta_schedule(S)
+    save("beta_schedules", **out)
+
+
 def gen_qsample():
     """The reference's own free functions q_sample / extract_x0 (task/diffusion.py:31-64) on seeded inputs."""
     RI.import_reference_model()
@@ -228,6 +241,9 @@ if __name__ == "__main__":
     if "--qsample-only" in sys.argv:
         gen_qsample()
         sys.exit(0)
+    if "--betas-only" in sys.argv:
+        gen_beta_schedules()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
@@ -235,3 +251,4 @@ if __name__ == "__main__":
     gen_extra_samplers()
     gen_notes()
     gen_qsample()
+    gen_beta_schedules()

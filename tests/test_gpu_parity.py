@@ -495,6 +495,38 @@ def test_ragged_shapes_vs_oracle(k, precision):
         assert d <= ATOL_STEP, (B, Tn, d)
 
 
+def test_cosine_beta_schedule_steps_vs_oracle(golden_dir):
+    """beta_schedule='cosine' (model/unet.py:558-567; betas pinned by tests/golden/beta_schedules.npz): the
+    engine only sees coefficient tables, so the same kernels run another schedule - three reverse steps
+    against the oracle fed with the reference's betas."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=3, kernel_size=9, timesteps=50)
+    p = R.synthetic_params(hp, seed=21)
+    m = ClassifierFreeDiffRoll(
+        residual_channels=64, unconditional=False, condition="fixed", n_mels=hp["n_mels"], norm_args=[0, 1, "imagewise"],
+        residual_layers=3, kernel_size=9, dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
+        spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000),
+        timesteps=50, training={"mode": "x_0"}, sampling={"type": "cfdg_ddpm_x0", "w": 0.5}, beta_schedule="cosine")
+    m.load_state_dict(p)
+    betas = T(np.load(os.path.join(golden_dir, "beta_schedules.npz"))["cosine_50"])
+    assert torch.equal(m.betas, betas)
+    sch = R.schedule(0.0, 0.0, 50, betas=betas)
+    torch.manual_seed(4)
+    B, Tn = 2, 60
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(3, B, 1, Tn, 88)
+    ref, out = x, x
+    with torch.no_grad():
+        spec = R.frontend(wav, hp, Tn)
+        for i, t in enumerate((30, 29, 28)):
+            ref = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", ref, spec, t, z[i], 0.5)
+    for i, t in enumerate((30, 29, 28)):
+        out, _ = m.reverse_diffusion(out, wav, t, noise=z[i])
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
 def test_q_sample_extract_x0_bit_exact(golden_dir):
     """diffroll_amd.q_sample / extract_x0 (dr_q_sample / dr_extract_x0) against the reference's free functions'
     outputs (task/diffusion.py:31-64): same operation order, one rounding per operation -> bit-exact; also

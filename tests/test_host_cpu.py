@@ -292,3 +292,18 @@ def test_note_metrics_against_exhaustive_matching():
     # two estimates competing for one reference note: only one can be matched
     p, r, f = M.evaluate_notes(i[:1], hz[:1], np.array([[0.0, 0.4], [0.032, 0.4]]), hz[[0, 0]])
     assert (p, r) == (0.5, 1.0)
+
+
+def test_extra_beta_schedules_bit_equal(golden_dir):
+    """cosine / quadratic / sigmoid beta schedules (model/unet.py:558-579) == the reference's outputs, and
+    make_schedule(betas=...) feeds them through the same table builder."""
+    from diffroll_amd import schedule as S
+    g = np.load(os.path.join(golden_dir, "beta_schedules.npz"))
+    for n in (50, 200):
+        assert torch.equal(S.cosine_beta_schedule(n), torch.from_numpy(g[f"cosine_{n}"]))
+        assert torch.equal(S.quadratic_beta_schedule(n), torch.from_numpy(g[f"quadratic_{n}"]))
+        assert torch.equal(S.sigmoid_beta_schedule(n), torch.from_numpy(g[f"sigmoid_{n}"]))
+    sch = S.make_schedule(0.0, 0.0, 50, betas=S.cosine_beta_schedule(50))
+    assert torch.equal(sch["betas"], torch.from_numpy(g["cosine_50"]))
+    tab = S.posterior_coef_table(sch)
+    assert tab.shape == (50, 5) and bool(torch.isfinite(tab).all())
