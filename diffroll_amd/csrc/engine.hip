@@ -423,7 +423,14 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
             allow_splitk(e, a);
-            HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, pick_pointwise_tile(Cp / 64, NB, T, prec), st, prec));
+            Tile tile = pick_pointwise_tile(Cp / 64, NB, T, prec);
+            // the last layer's residual output is never read (model/diffwave.py:678-682 only uses the skip sum
+            // after the loop): launch the skip half of the M tiles only
+            if (l + 1 == L && tile.flavor == 2) {
+                const Tile half = pick_pointwise_tile(Cp / 128, NB, T, prec);
+                if (half.flavor == 2) { tile = half; a.MT = Cp / 128; a.mt0 = Cp / 128; }
+            }
+            HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, tile, st, prec));
         }
     }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)

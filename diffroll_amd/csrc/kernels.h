@@ -49,6 +49,7 @@ struct GemmArgs {
     int taps, dil;           // conv taps (odd) and dilation; halo = (taps-1)/2*dil
     int kchunks;             // ceil(Cin/32)
     int MT;                  // M tiles of 128 packed rows
+    int mt0;                 // pw_kernel only: first M tile of the launch (tiles mt0 .. mt0 + MT - 1 are computed)
     // output
     float* Y;
     long y_bs, y_ps, y_fs;

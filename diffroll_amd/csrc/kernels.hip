@@ -756,6 +756,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
         mt = blockIdx.x % a.MT;
         nt = blockIdx.x / a.MT;
     }
+    mt += a.mt0;    // launches over a sub-range of the M tiles (the last layer only needs its skip rows)
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
