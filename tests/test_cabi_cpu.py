@@ -74,3 +74,37 @@ def test_no_gpu_fails_loudly(lib):
         m.engine
     with pytest.raises(EngineError):
         m(torch.zeros(1, 1, 8, 88), torch.zeros(1, 4096), torch.zeros(1, dtype=torch.long))
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/diffroll_amd.h is the whole boundary: it must compile as C99 (no C++, no torch/HIP types) and a
+    plain C program must link against the library and call it (version query and a failing create: no GPU here)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from diffroll_amd import _cabi
+    src = tmp_path / "cabi_probe.c"
+    src.write_text(r"""
+        #include <stdio.h>
+        #include <string.h>
+        #include "diffroll_amd.h"
+        int main(void) {
+            dr_config cfg;
+            memset(&cfg, 0, sizeof cfg);
+            cfg.abi_version = DR_ABI_VERSION + 1000;          /* wrong on purpose */
+            dr_engine* e = NULL;
+            int rc = dr_create(&e, &cfg);
+            printf("abi %d create_rc %d err '%s'\n", dr_abi_version(), rc, dr_last_error(NULL));
+            return (dr_abi_version() == DR_ABI_VERSION && rc != 0 && e == NULL) ? 0 : 1;
+        }
+    """)
+    exe = tmp_path / "cabi_probe"
+    libdir = os.path.dirname(_cabi.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-ldiffroll_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "ABI version mismatch" in r.stdout
