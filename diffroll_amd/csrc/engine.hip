@@ -80,6 +80,9 @@ struct dr_engine {
     size_t cond_cap = 0;
     float* cond = nullptr;
     float* cond_dummy = nullptr;   // one sample of readable memory for generation (no dr_frontend): never used
+    // condition='trainable_spec': per-layer conditioner of the learned unconditional spectrogram, [L][2Cp/4][T][4]
+    float* cond_tr = nullptr;
+    int cond_tr_T = 0;
     // front-end workspace
     size_t fe_cap_wav = 0, fe_cap_pow = 0, fe_cap_log = 0, fe_cap_spec = 0, fe_cap_mm = 0;
     float *wav_pad = nullptr, *power = nullptr, *logmel = nullptr, *specP4 = nullptr, *mm = nullptr;
@@ -230,6 +233,7 @@ size_t expected_numel(const dr_engine* e, const std::string& name) {
     if (name == "skip_projection.bias") return C;
     if (name == "output_projection.weight") return 88 * C;
     if (name == "output_projection.bias") return 88;
+    if (name == "trainable_parameters") return NM * 641;      // condition='trainable_spec' (model/diffwave.py:601)
     const std::string pre = "residual_layers.";
     if (name.compare(0, pre.size(), pre) == 0) {
         const size_t dot = name.find('.', pre.size());
@@ -338,6 +342,35 @@ void p4_out(GemmArgs& a, float* Y, int planes, int T, int rows) {
     a.Y = Y; a.y_bs = (long)planes * T * 4; a.y_ps = (long)T * 4; a.y_fs = 4; a.y_rows = rows;
 }
 
+// condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch feeds the learned
+// (n_mels, 641) spectrogram, trimmed to the roll length, through every layer's conditioner projection.  Like the
+// conditional tensors it is hoisted: [L][2Cp/4][T][4], rebuilt when T changes (one-time, null stream).
+int build_trainable_cond(dr_engine* e, int T) {
+    const std::vector<float>* P = find_param(e, "trainable_parameters");
+    if (!P) return DR_OK;
+    if (e->cond_tr && e->cond_tr_T == T) return DR_OK;
+    if (T > 641) return fail(e, DR_EINVAL, "condition='trainable_spec' holds 641 frames, roll has %d", T);
+    const int NM = e->NM, Cp = e->Cp, mel_planes = (NM + 3) / 4;
+    std::vector<float> sp((size_t)mel_planes * T * 4, 0.f);      // P4 image of P[:, :T]
+    for (int m = 0; m < NM; ++m)
+        for (int t = 0; t < T; ++t) sp[((size_t)(m >> 2) * T + t) * 4 + (m & 3)] = (*P)[(size_t)m * 641 + t];
+    float* d_sp = nullptr;
+    int rc;
+    if ((rc = dev_alloc(e, &d_sp, sp.size(), false))) return rc;
+    HIPCHK(e, hipMemcpy(d_sp, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(e, &e->cond_tr, (size_t)e->L * 2 * Cp * T))) { (void)hipFree(d_sp); return rc; }
+    for (int l = 0; l < e->L; ++l) {
+        const LayerW& w = e->layers[l];
+        GemmArgs a = p4_gemm(w.cond_w, w.cond_b, Cp / 64, d_sp, mel_planes, 1, T);
+        p4_out(a, e->cond_tr + (size_t)l * 2 * Cp * T, 2 * Cp / 4, T, 2 * Cp);
+        HIPCHK(e, launch_gemm(a, EPI_PLAIN, 2, nullptr));
+    }
+    HIPCHK(e, hipDeviceSynchronize());
+    (void)hipFree(d_sp);
+    e->cond_tr_T = T;
+    return DR_OK;
+}
+
 int ensure_workspace(dr_engine* e, int NB, int T) {
     if (NB <= e->ws_NB && T == e->ws_T) return DR_OK;
     const int nb = std::max(NB, e->ws_T == T ? e->ws_NB : 0);
@@ -355,6 +388,7 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     if ((rc = dev_alloc(e, &e->cond_dummy, (size_t)2 * e->Cp * T))) return rc;
     e->ws_NB = nb;
     e->ws_T = T;
+    if ((rc = build_trainable_cond(e, T))) return rc;
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     e->gkey = GraphKey{};
@@ -393,6 +427,10 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             GemmArgs a = p4_gemm(prec ? w.conv_w3 : w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
             if (prec) s3_in(a, e->hd3);
             a.bias2 = zero_spec ? w.conv_b_z : w.conv_b_u;   // samples >= n_cond: spec == 0 or spec == -1
+            if (e->cond_tr && !zero_spec) {                  // ... or the learned unconditional spectrogram
+                a.cond2 = e->cond_tr + (size_t)l * 2 * Cp * T;
+                a.bias2 = w.conv_b;
+            }
             a.taps = e->K; a.dil = w.dil;
             a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
             a.c_bs = (long)2 * Cp * T;
@@ -573,7 +611,7 @@ void dr_destroy(dr_engine* e) {
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
-                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt, e->xwork};
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt, e->xwork, e->cond_tr};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -620,6 +658,8 @@ int dr_commit(dr_engine* e, void* stream) {
     for (void* p : e->owned) (void)hipFree(p);
     e->owned.clear();
     e->layers.assign(L, LayerW{});
+    e->cond_tr_T = 0;       // rebuilt from the new conditioner weights / trainable_parameters at the next use
+    e->ws_T = 0;            // (ensure_workspace is where that happens)
     int rc;
     auto P = [&](const std::string& n) -> const std::vector<float>& { return *find_param(e, n); };
 

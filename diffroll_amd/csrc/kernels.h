@@ -63,6 +63,8 @@ struct GemmArgs {
     const float* cond;       // EPI_GATE: [n_cond][MT*32 planes][T][4] in packed-row order; must point at valid memory
                              // of at least one sample even when n_cond == 0 (prefetched unconditionally, then ignored)
     long c_bs;
+    const float* cond2;      // EPI_GATE, optional: one conditioner tensor [MT*32 planes][T][4] shared by all samples >= n_cond
+                             // (the learned unconditional spectrogram of condition='trainable_spec'); null: they use bias2 only
     int n_cond;
     int dual;                // EPI_GATE, gemm_kernel only: > 0 = also write sample b + dual from the same accumulators
                              // with the unconditional bias (first layer under classifier-free guidance); NB counts b only

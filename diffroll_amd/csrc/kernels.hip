@@ -614,7 +614,9 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 // conditioner quads of this frame column: one unconditional batch (unconditional samples read
                 // sample 0's tensor - valid memory - and ignore it)
                 const int tc = min(t, a.T - 1);
-                const float* cb = a.cond + (long)(be < a.n_cond ? be : 0) * a.c_bs + (long)tc * 4;
+                // samples >= n_cond: the shared learned unconditional conditioner (condition='trainable_spec') when
+                // there is one, else sample 0's tensor as a readable dummy
+                const float* cb = ((be < a.n_cond || !a.cond2) ? a.cond + (long)(be < a.n_cond ? be : 0) * a.c_bs : a.cond2) + (long)tc * 4;
     #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
     #pragma unroll
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                         float b0[4], b1[4], c0v[4], c1v[4];
                         f4arr(ebias[0][q], b0); f4arr(ebias[0][q + 2], b1);
                         f4arr(eop[0][ni][q], c0v); f4arr(eop[0][ni][q + 2], c1v);
-                        const bool has_c = be < a.n_cond;
+                        const bool has_c = be < a.n_cond || a.cond2 != nullptr;
     #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float a0 = has_c ? b0[e] + c0v[e] : b0[e];
@@ -1132,11 +1134,11 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
         if constexpr (EPI == EPI_GATE) {
             float4 cnd[RT];
             const int tc = min(t, a.T - 1);
-            const float* cb = a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs + (long)tc * 4;
+            const float* cb = ((b < a.n_cond || !a.cond2) ? a.cond + (long)(b < a.n_cond ? b : 0) * a.c_bs : a.cond2) + (long)tc * 4;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) cnd[rt] = *reinterpret_cast<const float4*>(cb + (long)((rowb + rt * 16) >> 2) * a.T * 4);
             if (t >= a.T) continue;
-            const bool has_c = b < a.n_cond;
+            const bool has_c = b < a.n_cond || a.cond2 != nullptr;
             {                                    // tile 0 = gate rows, tile 1 = filter rows of the same 16 channels
                 const int c0 = mt * 64 + wr * 16 + kq * 4;
                 if (c0 >= a.y_rows) continue;

@@ -106,10 +106,11 @@ class ClassifierFreeDiffRoll(nn.Module):
                  precision="f32",
                  beta_schedule="linear"):
         super().__init__()
-        if condition not in ("fixed",):
-            if condition in ("trainable_spec", "trainable_z"):
+        if condition not in ("fixed", "trainable_spec"):
+            if condition == "trainable_z":
                 raise NotImplementedError(
-                    f"condition='{condition}' is outside the sampling hot path (SURVEY.md 2.1 #9)")
+                    "condition='trainable_z' cannot be constructed in the reference either (model/diffwave.py:619 "
+                    "passes kernel_size into ResidualBlockz's `uncond`; SURVEY.md Appendix B)")
             raise ValueError(f"unrecognized condition '{condition}'")        # model/diffwave.py:610
         if unconditional:
             raise NotImplementedError("unconditional=True (no conditioner) is not on the sampling hot path")
@@ -131,6 +132,8 @@ class ClassifierFreeDiffRoll(nn.Module):
             raise ValueError(f"unknown beta_schedule '{beta_schedule}'")
         self.spec_dropout = spec_dropout
 
+        if condition == "trainable_spec":                                    # model/diffwave.py:600-604
+            self.trainable_parameters = nn.Parameter(torch.full((int(spec_args.get("n_mels", n_mels)), 641), -1.0))
         # parameter containers, same names/shapes/initialisation as the reference
         self.input_projection = _conv1d(88, residual_channels, 1)
         self.diffusion_embedding = _DiffusionEmbedding()
@@ -247,7 +250,12 @@ class ClassifierFreeDiffRoll(nn.Module):
         if not bool((diffusion_step == t).all()):
             raise NotImplementedError("per-sample diffusion steps are not used by the samplers (task/diffusion.py:947)")
         B, _, T, K = x_t.shape
-        if sampling is True:
+        if sampling is True and self.hparams.condition == "trainable_spec":
+            # the learned unconditional spectrogram replaces the clip's (model/diffwave.py:656-658); it is 2-D and
+            # 641 frames long, and trim_spec_roll (:662) trims the roll to it
+            Tm = min(T, 641)
+            spec = self.trainable_parameters.detach()[:, :Tm].to(eng.device, torch.float32)
+        elif sampling is True:
             TF = waveform.shape[-1] // eng.hop_length + 1
             Tm = min(T, TF)
             spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
@@ -270,6 +278,8 @@ class ClassifierFreeDiffRoll(nn.Module):
             Tm = spec.shape[-1]
         else:
             Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
+            if self.hparams.condition == "trainable_spec":
+                Tm = min(T, 641)
         xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         z = None
@@ -340,6 +350,9 @@ class ClassifierFreeDiffRoll(nn.Module):
         else:
             Tm = T if waveform is None else min(T, waveform.shape[-1] // eng.hop_length + 1)
             spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
+            if self.hparams.condition == "trainable_spec":
+                Tm = min(T, 641)
+                spec = self.trainable_parameters.detach()[:, :Tm].to(eng.device, torch.float32)
         # a fresh roll buffer per call: the engine's captured chain runs on its own work buffer, so caller
         # addresses never force a re-capture
         xb = x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].clone(memory_format=torch.contiguous_format)

@@ -200,6 +200,16 @@ def frontend(waveform: Tensor, hp: dict, T_roll: int, sampling: bool = False,
     return spec[..., :T_min]
 
 
+def uncond_spec(params: Dict[str, Tensor], hp: dict, like: Tensor) -> Tensor:
+    """The spectrogram of the unconditional branch (forward(sampling=True), model/diffwave.py:656-660):
+    all -1 for condition 'fixed'; for condition 'trainable_spec' the learned (n_mels, 641) parameter, trimmed to
+    the roll length (trim_spec_roll, :30-39) and broadcast over the batch (the reference feeds it 2-D)."""
+    if hp.get("condition", "fixed") == "trainable_spec":
+        T = like.shape[-1]
+        return params["trainable_parameters"][:, :T].unsqueeze(0).expand(like.shape[0], -1, -1)
+    return torch.full_like(like, -1)
+
+
 # --------------------------------------------------------------------------
 # network  (model/diffwave.py:134-151, :664-686)
 # --------------------------------------------------------------------------
@@ -251,6 +261,8 @@ def forward(params: Dict[str, Tensor], hp: dict, x_t: Tensor, waveform: Tensor, 
             table: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """ClassifierFreeDiffRoll.forward in eval mode (model/diffwave.py:637-686)."""
     spec = frontend(waveform, hp, x_t.shape[2], sampling, inpainting_t, inpainting_f)
+    if sampling:
+        spec = uncond_spec(params, hp, spec)
     return denoise(params, hp, x_t, spec, t, table), spec
 
 
@@ -331,11 +343,11 @@ def reverse_step(params, hp, sch, sampler: str, x: Tensor, spec_c: Optional[Tens
     t = torch.tensor(t_index).repeat(B)
     if sampler in ("cfdg_ddpm_x0", "inpainting_ddpm_x0"):
         x0_c = denoise(params, hp, x, spec_c, t, table)
-        x0_u = denoise(params, hp, x, torch.full_like(spec_c, -1), t, table)
+        x0_u = denoise(params, hp, x, uncond_spec(params, hp, spec_c), t, table)
         x0 = (1 + w) * x0_c - w * x0_u                      # :953 / :1009
     elif sampler == "generation_ddpm_x0":
         T = x.shape[2]
-        spec_u = torch.full((B, int(hp["n_mels"]), T), -1.0)
+        spec_u = uncond_spec(params, hp, torch.empty(B, int(hp["n_mels"]), T))
         x0 = denoise(params, hp, x, spec_u, t, table)         # :979-980
     elif sampler == "ddpm_x0":
         x0 = denoise(params, hp, x, spec_c, t, table)         # :839
@@ -416,6 +428,8 @@ def synthetic_params(hp: dict, seed: int = 0) -> Dict[str, Tensor]:
     p["skip_projection.bias"] = unif((C,), C)
     p["output_projection.weight"] = torch.randn(88, C, 1, generator=g) * 0.02
     p["output_projection.bias"] = unif((88,), C)
+    if hp.get("condition", "fixed") == "trainable_spec":      # model/diffwave.py:601 (initialised to -1; here: "trained")
+        p["trainable_parameters"] = torch.rand(M, 641, generator=g) * 2 - 1
     return p
 
 

@@ -197,6 +197,34 @@ def gen_notes():
     save("notes", n=len(rolls), **out)
 
 
+def gen_trainable_spec():
+    """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch feeds a learned
+    (n_mels, 641) spectrogram instead of -1.  forward(sampling=True), one cfdg step and one generation step."""
+    hp = hp_small(9, C=32, L=3, S=8)
+    hp["condition"] = "trainable_spec"
+    params = R.synthetic_params(hp, seed=909)
+    B, T = 2, 24
+    torch.manual_seed(71)
+    wav = 0.1 * torch.randn(B, T * 512)
+    x = torch.randn(B, 1, T, 88)
+    z = torch.randn(B, 1, T, 88)
+    out = dict(hp=json.dumps(hp), seed=909, wsum=weight_checksum(params), wav=wav, x=x, z=z, w=0.5)
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+    RI.load_params(m, params)
+    with torch.no_grad():
+        t = torch.tensor(5).repeat(B)
+        x0_u, spec_u = m(x, torch.zeros_like(wav), t, sampling=True)
+        out["x0_u"], out["spec_u"] = x0_u, spec_u
+        with RI.injected_noise([z]):
+            out["cfdg_t5"], _ = m.reverse_diffusion(x, wav, 5)
+    m = RI.build_reference(hp, "generation_ddpm_x0", 0.0)
+    RI.load_params(m, params)
+    with torch.no_grad():
+        with RI.injected_noise([z]):
+            out["generation_t5"], _ = m.reverse_diffusion(x, wav, 5)
+    save("trainable_spec", **out)
+
+
 def gen_beta_schedules():
     """The extra beta schedules of model/unet.py:558-579, run from the reference."""
     RI.import_reference_model()
@@ -244,6 +272,9 @@ if __name__ == "__main__":
     if "--betas-only" in sys.argv:
         gen_beta_schedules()
         sys.exit(0)
+    if "--trainable-only" in sys.argv:
+        gen_trainable_spec()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
@@ -252,3 +283,4 @@ if __name__ == "__main__":
     gen_notes()
     gen_qsample()
     gen_beta_schedules()
+    gen_trainable_spec()

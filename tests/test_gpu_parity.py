@@ -495,6 +495,50 @@ def test_ragged_shapes_vs_oracle(k, precision):
         assert d <= ATOL_STEP, (B, Tn, d)
 
 
+def test_trainable_spec_condition_golden(golden_dir):
+    """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch reads the learned
+    (n_mels, 641) spectrogram through every layer's conditioner (hoisted like the clip's); forward(sampling=True),
+    a guided step (incl. the shared first-layer contraction) and a generation step against the reference run."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    g = np.load(os.path.join(golden_dir, "trainable_spec.npz"))
+    hp = json.loads(str(g["hp"]))
+    p = R.synthetic_params(hp, seed=int(g["seed"]))
+
+    def build(sampler, w):
+        m = ClassifierFreeDiffRoll(
+            residual_channels=hp["residual_channels"], unconditional=False, condition="trainable_spec", n_mels=hp["n_mels"],
+            norm_args=[0, 1, "imagewise"], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
+            dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
+            spec_args=dict(sample_rate=16000, n_fft=hp["n_fft"], hop_length=hp["hop_length"], n_mels=hp["n_mels"], f_min=0,
+                           f_max=8000), timesteps=hp["timesteps"], training={"mode": "x_0"},
+            sampling={"type": sampler, "w": w})
+        m.load_state_dict(p)
+        return m
+
+    x, wav, z = T(g["x"]), T(g["wav"]), T(g["z"])
+    t = torch.tensor(5).repeat(x.shape[0])
+    m = build("cfdg_ddpm_x0", 0.5)
+    x0_u, spec_u = m(x, torch.zeros_like(wav), t, sampling=True)
+    assert spec_u.dim() == 2 and torch.equal(spec_u.cpu(), T(g["spec_u"]))
+    assert maxdiff(x0_u.cpu(), T(g["x0_u"])) <= ATOL_FWD
+    out, _ = m.reverse_diffusion(x, wav, 5, noise=z)
+    assert maxdiff(out.cpu(), T(g["cfdg_t5"])) <= ATOL_STEP
+    m = build("generation_ddpm_x0", 0.0)
+    out, _ = m.reverse_diffusion(x, wav, 5, noise=z)
+    assert maxdiff(out.cpu(), T(g["generation_t5"])) <= ATOL_STEP
+    # the parameter can be re-loaded: a second commit rebuilds the hoisted tensors
+    p2 = dict(p)
+    p2["trainable_parameters"] = torch.full_like(p["trainable_parameters"], -1.0)     # == condition 'fixed'
+    m.load_state_dict(p2)
+    hp_f = dict(hp)
+    hp_f["condition"] = "fixed"
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    with torch.no_grad():
+        ref = R.reverse_step(p, hp_f, sch, "generation_ddpm_x0", x, None, 5, z, 0.0)
+    out, _ = m.reverse_diffusion(x, wav, 5, noise=z)
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP
+
+
 def test_cosine_beta_schedule_steps_vs_oracle(golden_dir):
     """beta_schedule='cosine' (model/unet.py:558-567; betas pinned by tests/golden/beta_schedules.npz): the
     engine only sees coefficient tables, so the same kernels run another schedule - three reverse steps

@@ -130,3 +130,24 @@ def test_q_sample_extract_x0_bit_exact(golden_dir):
     assert torch.equal(xt, T_("xt"))
     x0b = R.extract_x0(T_("xt"), T_("eps"), T_("t"), T_("sac"), T_("s1m"))
     assert torch.equal(x0b, T_("x0_back"))
+
+
+def test_trainable_spec_condition(golden_dir):
+    """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): oracle vs the reference run."""
+    g = np.load(os.path.join(golden_dir, "trainable_spec.npz"))
+    hp = json.loads(str(g["hp"]))
+    p = R.synthetic_params(hp, seed=int(g["seed"]))
+    assert abs(float(sum(v.double().abs().sum().item() for v in p.values())) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    T_ = lambda k: torch.from_numpy(np.asarray(g[k]))
+    x, wav, z = T_("x"), T_("wav"), T_("z")
+    t = torch.tensor(5).repeat(x.shape[0])
+    with torch.no_grad():
+        x0_u, spec_u = R.forward(p, hp, x, torch.zeros_like(wav), t, sampling=True)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+        spec_c = R.frontend(wav, hp, x.shape[2])
+        cf = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, spec_c, 5, z, 0.5)
+        ge = R.reverse_step(p, hp, sch, "generation_ddpm_x0", x, None, 5, z, 0.0)
+    assert torch.equal(spec_u[0], T_("spec_u"))          # the reference returns it 2-D (n_mels, T)
+    assert float((x0_u - T_("x0_u")).abs().max()) <= 2e-5
+    assert float((cf - T_("cfdg_t5")).abs().max()) <= 2e-5
+    assert float((ge - T_("generation_t5")).abs().max()) <= 2e-5
