@@ -303,6 +303,25 @@ def test_batch_shard_bitwise_without_splitk():
     assert r.stdout.strip().endswith("BITWISE 1"), r.stdout[-500:]
 
 
+def test_large_batch_self_consistency(full_model):
+    """Far beyond the oracle's reach (96 clips x 640 frames, k=9, guided: 192 evaluations per step, 1280-block
+    launches): every clip of the big batch equals the same clip run in a batch of four (independent units,
+    Philox keyed by the global index) to fp32 round-off, and everything is finite."""
+    hp, p, _ = full_model
+    hp3 = dict(hp)
+    hp3["timesteps"] = 3
+    m = make_model(hp3, p, sampler="cfdg_ddpm_x0", w=0.5)
+    g = torch.Generator().manual_seed(0)
+    B, Tn = 96, 640
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    big, _ = m.sample(x, wav, seed=5)
+    assert bool(torch.isfinite(big).all())
+    for lo in (0, 40, 92):
+        small, _ = m.sample(x[lo:lo + 4], wav[lo:lo + 4], seed=5, first_sample=lo)
+        assert maxdiff(big[lo:lo + 4].cpu(), small.cpu()) <= ATOL_STEP / 4
+
+
 def test_cfg_weight_zero_equals_conditional_sampler(full_model):
     """(1+w) c - w u with w = 0 is c: cfdg_ddpm_x0(w=0) == ddpm_x0 (task/diffusion.py:953).  The two run with
     different batch geometry (2B vs B evaluations), i.e. possibly different contraction orders: round-off."""
