@@ -528,6 +528,7 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
 int check_ready(dr_engine* e, int sampler, int B, int T) {
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
+    HIPCHK(e, hipSetDevice(e->cfg.device));      // every entry point runs on the engine's device, whatever is current
     if (sampler != DR_SAMPLER_GENERATION_DDPM_X0 && (e->fe_B != B || e->fe_T != T))
         return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
                     e->fe_B, e->fe_T, B, T);
@@ -847,6 +848,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
                 int mask_f1, float* d_spec_out, void* stream) {
     if (!e || !d_wav) return fail(e, DR_EINVAL, "null argument");
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const int N = e->cfg.n_fft, hop = e->cfg.hop_length, pad = N / 2;
     if (B <= 0 || L <= pad || T_roll <= 0) return fail(e, DR_EINVAL, "bad front-end shape B=%d L=%d T=%d", B, L, T_roll);
