@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 3
+DR_ABI_VERSION = 4
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
 
 SAMPLERS = {
@@ -31,7 +31,7 @@ PRECISIONS = {"f32": 0, "bf16x3": 1}
 # every symbol include/diffroll_amd.h declares
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
-    "dr_commit", "dr_frontend", "dr_forward", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
+    "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
     "dr_extract_x0", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
 ]
@@ -80,6 +80,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_frontend.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.dr_forward.restype = C.c_int
     lib.dr_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    lib.dr_forward_steps.restype = C.c_int
+    lib.dr_forward_steps.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, vp, vp]
     lib.dr_step.restype = C.c_int
     lib.dr_step.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, vp]
     lib.dr_sample.restype = C.c_int

@@ -95,6 +95,8 @@ struct dr_engine {
     unsigned long long* d_counts = nullptr;   // dr_frame_counts accumulator
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
     DynParams* d_dyn = nullptr;         // per-call scalars of the captured chain (seed, batch offset, guidance weight)
+    int* d_tsel = nullptr;              // per-sample steps of dr_forward_steps
+    size_t tsel_cap = 0;
     bool use_dyn = false;               // set while the chain is being captured: run_step points the update at d_dyn
 
     // profiling of the dominant kernel
@@ -398,7 +400,8 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
 // One network evaluation for NB samples (first n_cond conditional) at step t.
 //   xin (B,T,88) rows are used modulo bmod (classifier-free batching: 2B evaluations of B inputs).
 int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, int T, int t, float* x0_out,
-                hipStream_t st, bool zero_spec = false) {
+                hipStream_t st, bool zero_spec = false, const int* tsel = nullptr) {
+    // tsel (device, NB ints): per-sample diffusion steps (forward() with a (B,) step tensor); else step t for all
     const int Cp = e->Cp, P = Cp / 4, L = e->L;
     const int prec = e->prec;
     const long act_bs = (long)Cp * T, s3_bs = act_bs + act_bs / 2;   // per-sample sizes (4-byte units)
@@ -415,7 +418,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
         p4_out(a, e->h, P, T, Cp);
         // hd = h + d_0 (model/diffwave.py:138-139), fp32 P4 or split-bf16 for the first dilated conv
-        a.d2 = e->d_dtab + (size_t)t * L * Cp;
+        a.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
+        a.tsel = tsel; a.d2_ts = (long)L * Cp;
         if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
         else { a.Y2 = e->hd; a.y2_bs = act_bs; }
         allow_splitk(e, a);
@@ -455,7 +459,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if (prec) s3_in(a, e->g3);
             p4_out(a, e->h, P, T, Cp);
             if (l + 1 < L) {
-                a.d2 = e->d_dtab + ((size_t)t * L + l + 1) * Cp;
+                a.d2 = e->d_dtab + ((tsel ? 0 : (size_t)t * L) + l + 1) * Cp;
+                a.tsel = tsel; a.d2_ts = (long)L * Cp;
                 if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
                 else { a.Y2 = e->hd; a.y2_bs = act_bs; }
             }
@@ -609,6 +614,7 @@ void dr_destroy(dr_engine* e) {
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
+    if (e->d_tsel) (void)hipFree(e->d_tsel);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
@@ -917,6 +923,29 @@ int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond, fl
     if (t < 0 || t >= e->S) return fail(e, DR_EINVAL, "step %d out of range", t);
     if ((rc = ensure_workspace(e, B, T))) return rc;
     return run_network(e, d_x, 0, B, cond == DR_COND_UNCOND ? 0 : B, T, t, d_x0_out, (hipStream_t)stream);
+}
+
+int dr_forward_steps(dr_engine* e, const float* d_x, int B, int T, const int32_t* host_t, int cond, float* d_x0_out,
+                     void* stream) {
+    if (!e || !d_x || !d_x0_out || !host_t) return fail(e, DR_EINVAL, "null argument");
+    const int sampler = cond == DR_COND_UNCOND ? DR_SAMPLER_GENERATION_DDPM_X0 : DR_SAMPLER_DDPM_X0;
+    int rc = check_ready(e, sampler, B, T);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b)
+        if (host_t[b] < 0 || host_t[b] >= e->S) return fail(e, DR_EINVAL, "step %d of sample %d out of range", host_t[b], b);
+    if ((rc = ensure_workspace(e, B, T))) return rc;
+    if ((size_t)B > e->tsel_cap) {
+        if (e->d_tsel) (void)hipFree(e->d_tsel);
+        e->d_tsel = nullptr;
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, (size_t)B * sizeof(int)));
+        e->d_tsel = (int*)q;
+        e->tsel_cap = (size_t)B;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(e, hipStreamSynchronize(st));       // the previous call may still be reading the step buffer
+    HIPCHK(e, hipMemcpy(e->d_tsel, host_t, (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+    return run_network(e, d_x, 0, B, cond == DR_COND_UNCOND ? 0 : B, T, 0, d_x0_out, st, false, e->d_tsel);
 }
 
 int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, int t, float w, uint64_t seed,

@@ -58,6 +58,8 @@ struct GemmArgs {
     float* Y2;               // EPI_RELU / residual rows of EPI_RES_SKIP: optional second output Y2 = Y + d2[row]
                              // (same strides): the (h + step embedding) tensor the next dilated conv reads
     const float* d2;         // [>= y_rows] never null (zero vector when unused)
+    const int* tsel;         // optional per-sample row selector of d2: sample b adds d2[tsel[b] * d2_ts + row] (per-sample
+    long d2_ts;              // diffusion steps of forward(); null in the samplers: one step for the whole batch)
     int y_rows;              // valid output rows (quads starting at >= y_rows are not written)
     // epilogue extras
     const float* cond;       // EPI_GATE: [n_cond][MT*32 planes][T][4] in packed-row order; must point at valid memory

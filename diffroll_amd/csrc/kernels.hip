@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         // residual rows only exist below y_rows; the clamp keeps the (unused) skip-row loads in range
                         const int p0 = min(mt * 128 + wr * WROWS + mi * 32 + 8 * q + 4 * hi, a.y_rows - 4);
-                        ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + p0);
+                        ed2[mi][q] = *reinterpret_cast<const float4*>(a.d2 + (a.tsel ? (long)a.tsel[be] * a.d2_ts : 0) + p0);
                     }
             }
         }
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             ebias[q] = *reinterpret_cast<const float4*>(a.bias + rowb + 8 * q);
-            ed2[q] = *reinterpret_cast<const float4*>(a.d2 + min(rowb + 8 * q, a.y_rows - 4));
+            ed2[q] = *reinterpret_cast<const float4*>(a.d2 + (a.tsel ? (long)a.tsel[b] * a.d2_ts : 0) + min(rowb + 8 * q, a.y_rows - 4));
         }
         const float* base = res_rows ? a.Y + (long)b * a.y_bs + (long)(rowb >> 2) * a.y_ps
                                      : a.skip + (long)b * a.s_bs + (long)((rowb - a.y_rows) >> 2) * a.T * 4;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
         for (int rt = 0; rt < RT; ++rt) {
             ebias[rt] = *reinterpret_cast<const float4*>(bsrc + rowb + rt * 16);
             if constexpr (EPI == EPI_RES_SKIP)
-                ed2[rt] = *reinterpret_cast<const float4*>(a.d2 + min(rowb + rt * 16, a.y_rows - 4));
+                ed2[rt] = *reinterpret_cast<const float4*>(a.d2 + (a.tsel ? (long)a.tsel[b] * a.d2_ts : 0) + min(rowb + rt * 16, a.y_rows - 4));
         }
     }
 #pragma unroll

@@ -139,6 +139,19 @@ class Engine:
                                             out.data_ptr(), self._stream()))
         return out
 
+    def forward_steps(self, x: torch.Tensor, steps, uncond: bool) -> torch.Tensor:
+        """x (B, T, 88), steps: B ints (one diffusion step per sample) -> x0 (B, T, 88)."""
+        x = self._dev(x)
+        B, T, K = x.shape
+        assert K == 88 and len(steps) == B
+        out = torch.empty_like(x)
+        arr = (C.c_int32 * B)(*[int(v) for v in steps])
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_forward_steps(self.h, x.data_ptr(), B, T, arr,
+                                                  _cabi.COND_UNCOND if uncond else _cabi.COND_SPEC,
+                                                  out.data_ptr(), self._stream()))
+        return out
+
     def step(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], t: int, w: float = 0.0,
              seed: int = 0, first_sample: int = 0) -> torch.Tensor:
         """In place on x (B, T, 88) (must already be a contiguous fp32 device tensor)."""

@@ -246,10 +246,12 @@ class ClassifierFreeDiffRoll(nn.Module):
         eng = self.engine
         if diffusion_step.dtype not in (torch.int32, torch.int64):
             raise NotImplementedError("fractional diffusion steps (lerp branch, model/diffwave.py:76-81) are off-path")
-        t = int(diffusion_step.flatten()[0].item())
-        if not bool((diffusion_step == t).all()):
-            raise NotImplementedError("per-sample diffusion steps are not used by the samplers (task/diffusion.py:947)")
+        steps = [int(v) for v in diffusion_step.flatten().tolist()]
         B, _, T, K = x_t.shape
+        if len(steps) != B:
+            raise ValueError(f"diffusion_step has {len(steps)} entries for a batch of {B}")
+        t = steps[0]
+        uniform = all(v == t for v in steps)      # the samplers' case (task/diffusion.py:947)
         if sampling is True and self.hparams.condition == "trainable_spec":
             # the learned unconditional spectrogram replaces the clip's (model/diffwave.py:656-658); it is 2-D and
             # 641 frames long, and trim_spec_roll (:662) trims the roll to it
@@ -263,7 +265,10 @@ class ClassifierFreeDiffRoll(nn.Module):
             spec = self._frontend(waveform, T, inpainting_t, inpainting_f)
             Tm = spec.shape[-1]
         x = x_t.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous()
-        x0 = eng.forward(x, t, uncond=(sampling is True))
+        if uniform:
+            x0 = eng.forward(x, t, uncond=(sampling is True))
+        else:                                      # one step per sample, as the reference's step() calls forward
+            x0 = eng.forward_steps(x, steps, uncond=(sampling is True))
         return x0.unsqueeze(1), spec
 
     # ------------------------------------------------------------------ samplers (one step)

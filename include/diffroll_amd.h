@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 3
+#define DR_ABI_VERSION 4
 
 enum {
     DR_OK = 0,
@@ -162,6 +162,12 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll,
  * d_x0_out (B, T, 88).  cond = DR_COND_SPEC needs a preceding dr_frontend with the same B, T. */
 int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond,
                float* d_x0_out, void* stream);
+
+/* The same with one diffusion step PER SAMPLE (host_t: B ints on the host), the general form of the reference's
+ * forward(x_t, waveform, diffusion_step (B,)) as its training / validation step() calls it; the samplers always
+ * pass one step for the whole batch.  Synchronises `stream` (the step vector is uploaded). */
+int dr_forward_steps(dr_engine* e, const float* d_x, int B, int T, const int32_t* host_t, int cond,
+                     float* d_x0_out, void* stream);
 
 /* One reverse-diffusion step t (in place on d_x).  d_noise (B, T, 88) is the z of that step
  * (ignored at t == 0); NULL -> on-device Philox keyed by (seed, first_sample + b, t). */

@@ -197,6 +197,23 @@ def gen_notes():
     save("notes", n=len(rolls), **out)
 
 
+def gen_forward_steps():
+    """forward() with one diffusion step PER SAMPLE, as step() calls it (task/diffusion.py:677-690)."""
+    hp = hp_small(9, C=32, L=5, S=8)
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+    params = R.synthetic_params(hp, seed=4242)
+    RI.load_params(m, params)
+    torch.manual_seed(81)
+    B, T = 4, 40
+    wav = 0.1 * torch.randn(B, T * 512)
+    x = torch.randn(B, 1, T, 88)
+    t = torch.tensor([5, 0, 7, 5])
+    with torch.no_grad():
+        x0_c, _ = m(x, wav, t)
+        x0_u, _ = m(x, torch.zeros_like(wav), t, sampling=True)
+    save("forward_steps", hp=json.dumps(hp), seed=4242, wsum=weight_checksum(params), wav=wav, x=x, t=t, x0_c=x0_c, x0_u=x0_u)
+
+
 def gen_trainable_spec():
     """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch feeds a learned
     (n_mels, 641) spectrogram instead of -1.  forward(sampling=True), one cfdg step and one generation step."""
@@ -275,6 +292,9 @@ if __name__ == "__main__":
     if "--trainable-only" in sys.argv:
         gen_trainable_spec()
         sys.exit(0)
+    if "--steps-only" in sys.argv:
+        gen_forward_steps()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
@@ -284,3 +304,4 @@ if __name__ == "__main__":
     gen_qsample()
     gen_beta_schedules()
     gen_trainable_spec()
+    gen_forward_steps()

@@ -514,6 +514,30 @@ def test_ragged_shapes_vs_oracle(k, precision):
         assert d <= ATOL_STEP, (B, Tn, d)
 
 
+def test_forward_with_per_sample_steps_golden(golden_dir):
+    """forward() with a (B,) step tensor whose entries differ (dr_forward_steps: the step-embedding row is
+    selected per sample in the epilogues) against the reference run; also at full width vs the oracle."""
+    g = np.load(os.path.join(golden_dir, "forward_steps.npz"))
+    hp, p, m = fixture_model(g)
+    x0_c, _ = m(T(g["x"]), T(g["wav"]), T(g["t"]))
+    x0_u, _ = m(T(g["x"]), T(g["wav"]), T(g["t"]), sampling=True)
+    assert maxdiff(x0_c.cpu(), T(g["x0_c"])) <= ATOL_FWD
+    assert maxdiff(x0_u.cpu(), T(g["x0_u"])) <= ATOL_FWD
+    for precision in ("f32", "bf16x3"):
+        hp2 = dict(R.DEFAULT_HP)
+        hp2.update(residual_channels=128, residual_layers=4, kernel_size=9, timesteps=20)
+        p2 = R.synthetic_params(hp2, seed=8)
+        m2 = make_model(hp2, p2, precision=precision)
+        torch.manual_seed(2)
+        wav = 0.1 * torch.randn(5, 200 * 512)
+        x = torch.randn(5, 1, 200, 88)
+        t = torch.tensor([19, 3, 3, 0, 11])
+        with torch.no_grad():
+            ref, _ = R.forward(p2, hp2, x, wav, t)
+        out, _ = m2(x, wav, t)
+        assert maxdiff(out.cpu(), ref) <= ATOL_FWD, precision
+
+
 def test_trainable_spec_condition_golden(golden_dir):
     """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch reads the learned
     (n_mels, 641) spectrogram through every layer's conditioner (hoisted like the clip's); forward(sampling=True),

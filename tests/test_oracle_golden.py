@@ -151,3 +151,16 @@ def test_trainable_spec_condition(golden_dir):
     assert float((x0_u - T_("x0_u")).abs().max()) <= 2e-5
     assert float((cf - T_("cfdg_t5")).abs().max()) <= 2e-5
     assert float((ge - T_("generation_t5")).abs().max()) <= 2e-5
+
+
+def test_forward_with_per_sample_steps(golden_dir):
+    """forward(x_t, waveform, diffusion_step (B,)) with different steps per sample vs the reference run."""
+    g = np.load(os.path.join(golden_dir, "forward_steps.npz"))
+    hp = json.loads(str(g["hp"]))
+    p = R.synthetic_params(hp, seed=int(g["seed"]))
+    T_ = lambda k: torch.from_numpy(np.asarray(g[k]))
+    with torch.no_grad():
+        x0_c, _ = R.forward(p, hp, T_("x"), T_("wav"), T_("t"))
+        x0_u, _ = R.forward(p, hp, T_("x"), torch.zeros_like(T_("wav")), T_("t"), sampling=True)
+    assert float((x0_c - T_("x0_c")).abs().max()) <= 2e-5
+    assert float((x0_u - T_("x0_u")).abs().max()) <= 2e-5
