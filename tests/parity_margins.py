@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Print the observed HIP-vs-oracle differences behind the tolerances of tests/test_gpu_parity.py."""
+"""Print the observed HIP-vs-oracle differences behind the tolerances of tests/test_gpu_parity.py
+(a script, not a test: `python tests/parity_margins.py` on an MI355X; it lives under tests/ because it uses the
+oracle, which only test code may import)."""
 import os
 import sys
 
