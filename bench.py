@@ -186,6 +186,17 @@ def main():
     }
     if rank == 0:
         assert out is not None and bool(torch.isfinite(out).all()) and out.shape == (world * B_LOCAL, 1, T, 88)
+        # the metric also asks for the HBM-roofline fraction: SURVEY.md 8(d) algorithmic bytes of one chain per GPU
+        # (weights streamed once per evaluation + layer-granular activation traffic + the update) over the chain time
+        C, Lr, k, M = HP["residual_channels"], HP["residual_layers"], HP["kernel_size"], 88
+        w_bytes = 4 * (M * C + C + Lr * (2 * C * C * k + 2 * C + 2 * C * C + 2 * C) + C * C + C + C * M + M)
+        a_uncond = M * 4 + Lr * (C * 4 + C * 4 + 2 * C * 4) + C * 4 + M * 4      # read h, write h, skip RMW per layer
+        a_cond = a_uncond + Lr * 2 * C * 4
+        chain_bytes = S * (2 * w_bytes + B_LOCAL * T * (a_cond + a_uncond + 3 * M * 4))
+        gbps = chain_bytes / (dt / args.steps) / 1e9
+        result["hbm_roofline"] = {"algorithmic_bytes_per_chain_per_gpu": chain_bytes, "achieved_gbps_per_gpu": round(gbps, 1),
+                                  "peak_gbps": 8000.0, "frac": round(gbps / 8000.0, 4),
+                                  "note": "the step is MFMA-bound in fp32 (see roofline); reported because the metric names it"}
 
     if rank == 0 and not args.no_roofline:
         eng = model.engine
