@@ -514,6 +514,39 @@ def test_ragged_shapes_vs_oracle(k, precision):
         assert d <= ATOL_STEP, (B, Tn, d)
 
 
+def test_random_configurations_vs_oracle():
+    """Randomised (fixed seed) sweep over what the launch heuristics key on: channel counts incl. ones that need
+    padding, depth, every odd kernel size 3..15, dilation base / bound (dilations up to 27), batch, ragged frame
+    counts, all nine samplers, guidance weight, both precisions - one reverse step each against the oracle."""
+    rng = np.random.default_rng(2024)
+    samplers = ["ddpm_x0", "cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0", "ddim_x0", "cfdg_ddim_x0",
+                "ddpm", "ddim", "ddim2ddpm"]
+    for case in range(36):
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=int(rng.choice([32, 64, 96, 128, 160])), residual_layers=int(rng.integers(1, 6)),
+                  kernel_size=int(rng.choice([3, 5, 7, 9, 11, 13, 15])), dilation_base=int(rng.choice([1, 2, 3])),
+                  dilation_bound=int(rng.integers(1, 5)), timesteps=int(rng.integers(2, 12)))
+        sampler = samplers[case % 9]
+        w = float(rng.choice([0.0, 0.5, 1.3]))
+        B, Tn = int(rng.integers(1, 6)), int(rng.integers(1, 300))
+        precision = "bf16x3" if case % 4 == 3 else "f32"
+        it = [Tn // 4, max(Tn // 2, Tn // 4 + 1)] if sampler == "inpainting_ddpm_x0" else None
+        p = R.synthetic_params(hp, seed=3000 + case)
+        m = make_model(hp, p, sampler=sampler, w=w, inpainting_t=it, precision=precision)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+        g = torch.Generator().manual_seed(case)
+        wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        z = torch.randn(B, 1, Tn, 88, generator=g)
+        t = int(rng.integers(0, hp["timesteps"]))
+        with torch.no_grad():
+            spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn, inpainting_t=it)
+            ref = R.reverse_step(p, hp, sch, sampler, x, spec, t, z, w)
+        out, _ = m.reverse_diffusion(x, wav, t, noise=z)
+        d = maxdiff(out.cpu(), ref)
+        assert d <= ATOL_STEP, (case, hp, sampler, w, B, Tn, t, precision, d)
+
+
 def test_forward_with_per_sample_steps_golden(golden_dir):
     """forward() with a (B,) step tensor whose entries differ (dr_forward_steps: the step-embedding row is
     selected per sample in the epilogues) against the reference run; also at full width vs the oracle."""
