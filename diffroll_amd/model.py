@@ -113,7 +113,9 @@ class ClassifierFreeDiffRoll(nn.Module):
                     "passes kernel_size into ResidualBlockz's `uncond`; SURVEY.md Appendix B)")
             raise ValueError(f"unrecognized condition '{condition}'")        # model/diffwave.py:610
         if unconditional:
-            raise NotImplementedError("unconditional=True (no conditioner) is not on the sampling hot path")
+            raise NotImplementedError("unconditional=True cannot run in the reference either: forward() still passes the "
+                                      "spectrogram to blocks built without a conditioner and trips the assertion at "
+                                      "model/diffwave.py:135-136")
         sampling = _attr(sampling if sampling is not None else {"type": "cfdg_ddpm_x0", "w": 0.0})
         training = _attr(training if training is not None else {"mode": "x_0"})
         spec_args = _attr(dict(spec_args))
