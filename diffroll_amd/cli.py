@@ -9,7 +9,7 @@
 Hydra is not a dependency: the same ``group=name`` / ``dotted.key=value`` override syntax is parsed here over
 defaults that restate config/sampling.yaml, config/task/{generation,transcription,inpainting}.yaml,
 config/model/ClassifierFreeDiffRoll.yaml and config/spec/mel.yaml.  Differences from the reference driver:
-no Lightning Trainer / TensorBoard; rolls are written as ``rolls_batch<i>.npy`` and MIDI files per sample;
+no Lightning Trainer / TensorBoard; rolls are written as ``rolls_batch<i>.npy`` plus ``raw_midi_<batch>_<i>.mid`` / ``clean_midi_e<batch>_<i>.mid``;
 audio ingestion (utils/custom_dataset.py:55-91) reads .wav only (no mp3 codec in this image) and resamples with
 scipy's polyphase filter instead of torchaudio's windowed-sinc kernel.
 """
@@ -185,7 +185,8 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
         roll = sample_sharded(model, x[lo:hi], waveform[lo:hi], seed=int(cfg["seed"]) + bi)
         if rank == 0:
             np.save(os.path.join(cfg["output_dir"], f"rolls_batch{bi}.npy"), roll.cpu().numpy())
-            model.export_midi(roll, os.path.join(cfg["output_dir"], f"raw_midi_{bi}_"))
+            model.export_midi(roll, os.path.join(cfg["output_dir"], f"raw_midi_{bi}_"),       # names of predict_step
+                              clean_prefix=os.path.join(cfg["output_dir"], f"clean_midi_e{bi}_"))
     torch.cuda.synchronize()
     if rank == 0:
         dt = time.perf_counter() - t0

@@ -91,17 +91,21 @@ def read_midi_notes(path: str) -> List[Tuple[int, int, int, int]]:
 
 
 def export_midi(engine, roll: torch.Tensor, path_prefix: str, threshold: float = 0.5, hop_length: int = 512,
-                sample_rate: int = 16000, generation_filter: float = 0.0) -> List[str]:
-    """roll (B,1,T,88) -> `<prefix><i>.mid` per sample, as predict_step does (task/diffusion.py:598-618):
-    frames -> seconds with hop/sr (the reference's predict_step uses a stale HOP_LENGTH = 160 constant there,
-    its test_step the model's hop: the model's hop is used here), bins -> MIDI numbers MIN_MIDI + bin, notes
-    shorter than generation_filter seconds dropped, velocity 127."""
+                sample_rate: int = 16000, generation_filter: float = 0.0, clean_prefix: str = None) -> List[str]:
+    """roll (B,1,T,88) -> per sample `<path_prefix><i>.mid` with every extracted note (the reference's raw_midi_*)
+    and, when clean_prefix is given, `<clean_prefix><i>.mid` without the notes not longer than generation_filter
+    seconds (its clean_midi_e*), as predict_step does (task/diffusion.py:598-618): frames -> seconds with hop/sr
+    (the reference's predict_step uses a stale HOP_LENGTH = 160 constant there, its test_step the model's hop: the
+    caller chooses), bins -> MIDI numbers MIN_MIDI + bin, velocity 127.  Returns the raw paths."""
     paths = []
     scaling = hop_length / sample_rate
     for i, (pitches, intervals) in enumerate(extract_notes_wo_velocity(engine, roll, threshold)):
         iv = intervals.astype(np.float64) * scaling
-        keep = (iv[:, 1] - iv[:, 0]) > generation_filter if len(iv) else np.zeros(0, dtype=bool)
         path = f"{path_prefix}{i}.mid"
-        save_midi(path, (MIN_MIDI + pitches[keep]).tolist(), iv[keep].tolist(), [127] * int(keep.sum()))
+        save_midi(path, (MIN_MIDI + pitches).tolist(), iv.tolist(), [127] * len(pitches))
         paths.append(path)
+        if clean_prefix is not None:
+            keep = (iv[:, 1] - iv[:, 0]) > generation_filter if len(iv) else np.zeros(0, dtype=bool)
+            save_midi(f"{clean_prefix}{i}.mid", (MIN_MIDI + pitches[keep]).tolist(), iv[keep].tolist(),
+                      [127] * int(keep.sum()))
     return paths

@@ -414,18 +414,20 @@ class ClassifierFreeDiffRoll(nn.Module):
         return {"Test/Frame_F1": f, "Test/Frame_precision": p, "Test/Frame_recall": r, "tp": tp, "fp": fp, "fn": fn,
                 "Test/Note_F1": note_f1, "note_scores": notes}
 
-    def export_midi(self, roll, path_prefix="raw_midi_", threshold=0.5, reference_timing=False):
+    def export_midi(self, roll, path_prefix="raw_midi_", threshold=0.5, reference_timing=False, clean_prefix=None):
         """Post-processing of predict_step (task/diffusion.py:598-618): threshold the final roll (the
         reference uses the function default 0.5 there, not hparams.frame_threshold), extract notes on the
-        GPU, drop notes shorter than hparams.generation_filter seconds and write one MIDI file per sample.
-        Note times use the model's hop (512 / 16000 s per frame); reference_timing=True reproduces the
-        reference's predict_step instead, which scales by its stale module constant HOP_LENGTH = 160
-        (task/diffusion.py:19,604: every time 3.2x too short, and the duration filter applied on that scale)."""
+        GPU and write per sample `<path_prefix><i>.mid` (all notes: the reference's raw_midi_{batch}_{i}.mid) and,
+        with clean_prefix, `<clean_prefix><i>.mid` without the notes not longer than hparams.generation_filter
+        seconds (its clean_midi_e{batch}_{i}.mid).  Note times use the model's hop (512 / 16000 s per frame);
+        reference_timing=True reproduces the reference's predict_step instead, which scales by its stale module
+        constant HOP_LENGTH = 160 (task/diffusion.py:19,604: every time 3.2x too short, and the duration filter
+        applied on that scale)."""
         from . import midi
         sa = self.hparams.spec_args
         hop = 160 if reference_timing else int(sa.get("hop_length", 512))
-        return midi.export_midi(self.engine, roll, path_prefix, threshold, hop,
-                                int(sa.get("sample_rate", 16000)), float(self.hparams.generation_filter))
+        return midi.export_midi(self.engine, roll, path_prefix, threshold, hop, int(sa.get("sample_rate", 16000)),
+                                float(self.hparams.generation_filter), clean_prefix)
 
     def sampling(self, batch, batch_idx=0):
         """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""

@@ -473,8 +473,13 @@ def test_note_extraction_bit_exact_and_midi(golden_dir, full_model, tmp_path):
             assert np.array_equal(pitches, np.asarray(op, dtype=np.int64))
     # batched call + export
     rolls = torch.stack([T(g["roll0"]), T(g["roll0"]).flip(1)])[:, None]
-    paths = midi.export_midi(eng, rolls, str(tmp_path / "raw_midi_"), threshold=0.5)
+    paths = midi.export_midi(eng, rolls, str(tmp_path / "raw_midi_"), threshold=0.5, generation_filter=0.1,
+                             clean_prefix=str(tmp_path / "clean_midi_e0_"))
     assert len(paths) == 2
+    clean = midi.read_midi_notes(str(tmp_path / "clean_midi_e0_0.mid"))
+    iv0 = g["intervals0_0.5"].reshape(-1, 2)
+    n_long = int(((iv0[:, 1] - iv0[:, 0]) * (512 / 16000) > 0.1).sum())
+    assert sum(1 for e in clean if e[1] == 0x90) == n_long       # the clean file drops the short notes only
     ev = midi.read_midi_notes(paths[0])
     n_notes = len(g["pitches0_0.5"])
     assert len(ev) == 2 * n_notes and sum(1 for e in ev if e[1] == 0x90) == n_notes
