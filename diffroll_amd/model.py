@@ -373,6 +373,47 @@ class ClassifierFreeDiffRoll(nn.Module):
         eng.sample(sampler, xb, z, w, seed, first_sample, use_graph)
         return xb.unsqueeze(1), spec
 
+    def sample_trajectory(self, x_T, waveform=None, noise=None, seed: int = 0, first_sample: int = 0):
+        """The same chain, keeping every intermediate roll on the device: returns (trajectory (timesteps, B, 1,
+        T', 88) with row i = x after step t = timesteps-1-i, spec).  This is what the reference's sampling()
+        collects as `noise_list` - on the host, with one D2H copy per step (task/diffusion.py:779-788) - for its
+        animation; here it is an opt-in eager loop over dr_step (one launch sequence per step, no graph), and the
+        last row equals sample()'s result bit for bit."""
+        eng = self.engine
+        sampler = self.hparams.sampling.type
+        S = int(self.hparams.timesteps)
+        B = x_T.shape[0]
+        x = x_T
+        rows = []
+        spec = None
+        for t in range(S - 1, -1, -1):
+            z = None if noise is None else noise[t]
+            if z is None and t > 0:       # Philox keyed by (seed, global sample, step): same draws as sample()
+                xx, spec = self._step_philox(sampler, x, waveform, t, seed, first_sample)
+            else:
+                xx, spec = self._one_step(sampler, x, waveform, t, z if t > 0 else torch.zeros_like(x))
+            rows.append(xx)
+            x = xx
+        return torch.stack(rows, 0), spec
+
+    def _step_philox(self, sampler, x, waveform, t_index, seed, first_sample):
+        eng = self.engine
+        B, _, T, _ = x.shape
+        spec = None
+        if sampler != "generation_ddpm_x0":
+            it = self.hparams.inpainting_t if sampler == "inpainting_ddpm_x0" else None
+            i_f = self.hparams.inpainting_f if sampler == "inpainting_ddpm_x0" else None
+            spec = self._frontend(waveform, T, it, i_f)
+            Tm = spec.shape[-1]
+        else:
+            Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
+            if self.hparams.condition == "trainable_spec":
+                Tm = min(T, 641)
+        xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
+        eng.step(sampler, xx, None, t_index, w, seed, first_sample)
+        return xx.unsqueeze(1), spec
+
     def predict_step(self, batch, batch_idx=0):
         """batch = (x_T, waveform[, ...]) as built by sampling.py:27-46.  Returns the final roll
         (B,1,T,88) (the reference returns nothing and writes figures/MIDI instead)."""

@@ -303,6 +303,24 @@ def test_batch_shard_bitwise_without_splitk():
     assert r.stdout.strip().endswith("BITWISE 1"), r.stdout[-500:]
 
 
+def test_sample_trajectory_matches_chain(golden_dir):
+    """sample_trajectory (every intermediate roll, the reference's noise_list of task/diffusion.py:779-788, kept
+    on the device) ends bit for bit where the captured chain ends - with injected noise and with Philox - and
+    its rows are the successive reverse steps."""
+    g = load(golden_dir, "steps_chain_k9")
+    hp, p, m = fixture_model(g, sampler="cfdg_ddpm_x0", w=float(g["w"]))
+    x, wav, noise = T(g["x"]), T(g["wav"]), T(g["noise"])
+    traj, _ = m.sample_trajectory(x, wav, noise=noise)
+    roll, _ = m.sample(x, wav, noise=noise)
+    S = hp["timesteps"]
+    assert traj.shape == (S,) + tuple(roll.shape) and torch.equal(traj[-1], roll)
+    assert maxdiff(traj[-1].cpu(), T(g["cfdg_ddpm_x0_chain"])) <= ATOL_STEP
+    assert maxdiff(traj[0].cpu(), T(g[f"cfdg_ddpm_x0_t{S - 1}"])) <= ATOL_STEP      # first row = the step from x_T
+    traj, _ = m.sample_trajectory(x, wav, seed=11, first_sample=3)
+    roll, _ = m.sample(x, wav, seed=11, first_sample=3)
+    assert torch.equal(traj[-1], roll)
+
+
 def test_large_batch_self_consistency(full_model):
     """Far beyond the oracle's reach (96 clips x 640 frames, k=9, guided: 192 evaluations per step, 1280-block
     launches): every clip of the big batch equals the same clip run in a batch of four (independent units,
