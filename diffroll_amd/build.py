@@ -51,7 +51,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             relink = True
         objs.append(o)
     if relink or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

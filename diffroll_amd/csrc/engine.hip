@@ -2,6 +2,8 @@
 // sequences, hipGraph capture of the reverse chain, and the C-ABI of include/diffroll_amd.h.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -128,6 +130,30 @@ int fail(dr_engine* e, int code, const char* fmt, ...) {
     } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// roctx ranges around the host-side phases (rocprofv3 --marker-trace shows them next to the kernel trace).  The
+// marker library is looked up at run time: no link-time dependency, silent no-ops when it is absent.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_GLOBAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+    explicit Range(const char* name) { if (roctx().push) roctx().push(name); }
+    ~Range() { if (roctx().pop) roctx().pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
 
 // ---- weight packing (layout: kernels.h) -------------------------------------------------------
 // get(prow, ch, tap) returns the (zero-padded) weight for packed row prow, input channel ch.
@@ -643,6 +669,7 @@ int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_c
 
 int dr_commit(dr_engine* e, void* stream) {
     if (!e) return DR_EINVAL;
+    Range range("dr_commit: pack + upload weights, hoisted tables");
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(e, hipSetDevice(e->cfg.device));
     if (e->h_emb.empty() || e->h_coef.empty()) return fail(e, DR_ESTATE, "dr_set_tables has not been called");
@@ -854,6 +881,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
                 int mask_f1, float* d_spec_out, void* stream) {
     if (!e || !d_wav) return fail(e, DR_EINVAL, "null argument");
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    Range range("dr_frontend: mel + conditioner projections");
     HIPCHK(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const int N = e->cfg.n_fft, hop = e->cfg.hop_length, pad = N / 2;
@@ -979,7 +1007,10 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         }
         return DR_OK;
     };
-    if (!use_graph || e->prof) return chain(d_x);
+    if (!use_graph || e->prof) {
+        Range range("dr_sample: eager chain");
+        return chain(d_x);
+    }
 
     GraphKey key;
     key.sampler = sampler; key.B = B; key.T = T; key.x = e->xwork; key.noise = d_noise;
@@ -989,6 +1020,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         if (!e->cap_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
         hipStream_t user = st;
         st = e->cap_stream;   // chain() launches on `st`
+        Range range("dr_sample: capture + instantiate the chain graph");
         HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         e->use_dyn = true;
         rc = chain(e->xwork);
@@ -1002,6 +1034,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->gkey = key;
     }
+    Range range("dr_sample: launch the chain graph");
     // the graph owns no caller address: x_T is copied in, the finished roll copied out (0.7 MB each way)
     HIPCHK(e, hipMemcpyAsync(e->xwork, d_x, per * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(e, launch_set_dyn(e->d_dyn, seed, first_sample, w, (float)(1.0 + (double)w), st));
