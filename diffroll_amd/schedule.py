@@ -19,29 +19,27 @@ def linear_beta_schedule(beta_start: float, beta_end: float, timesteps: int) -> 
     return torch.linspace(beta_start, beta_end, timesteps)
 
 
+_BETA_LO, _BETA_HI = 0.0001, 0.02     # the fixed end points of the quadratic / sigmoid schedules
+
+
 def cosine_beta_schedule(timesteps, s=0.008):
-    """model/unet.py:558-567 (https://arxiv.org/abs/2102.09672), same torch expressions."""
-    steps = timesteps + 1
-    x = torch.linspace(0, timesteps, steps)
-    alphas_cumprod = torch.cos(((x / timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
-    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
-    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
-    return torch.clip(betas, 0.0001, 0.9999)
+    """Nichol & Dhariwal's cosine schedule (arXiv:2102.09672) as model/unet.py:558-567 evaluates it: the
+    normalised squared-cosine curve f on timesteps + 1 grid points, beta_t = 1 - f[t+1] / f[t], clipped."""
+    grid = torch.linspace(0, timesteps, timesteps + 1)
+    f = torch.cos(((grid / timesteps) + s) / (1 + s) * torch.pi * 0.5) ** 2
+    f = f / f[0]
+    return torch.clip(1 - (f[1:] / f[:-1]), 0.0001, 0.9999)
 
 
 def quadratic_beta_schedule(timesteps):
-    """model/unet.py:570-573."""
-    beta_start = 0.0001
-    beta_end = 0.02
-    return torch.linspace(beta_start**0.5, beta_end**0.5, timesteps) ** 2
+    """model/unet.py:570-573: linear in sqrt(beta)."""
+    return torch.linspace(_BETA_LO**0.5, _BETA_HI**0.5, timesteps) ** 2
 
 
 def sigmoid_beta_schedule(timesteps):
-    """model/unet.py:575-579."""
-    beta_start = 0.0001
-    beta_end = 0.02
-    betas = torch.linspace(-6, 6, timesteps)
-    return torch.sigmoid(betas) * (beta_end - beta_start) + beta_start
+    """model/unet.py:575-579: a sigmoid ramp over [-6, 6] between the two end points."""
+    ramp = torch.sigmoid(torch.linspace(-6, 6, timesteps))
+    return ramp * (_BETA_HI - _BETA_LO) + _BETA_LO
 
 
 def make_schedule(beta_start: float, beta_end: float, timesteps: int, betas: torch.Tensor = None) -> Dict[str, torch.Tensor]:
