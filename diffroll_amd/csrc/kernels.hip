@@ -433,14 +433,17 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         for (int ni = 0; ni < NW; ++ni) o.v[ni] = Xb[g * 2 * FW + ni * 32];
         return o;
     };
+    // 8 channels of K for every frame tile: consecutive MFMAs go to different accumulators (the pinned schedule
+    // keeps program order inside its small groups: a chain of dependent back-to-back MFMAs costs ~8 cycles each)
     auto mma4 = [&](const float4 af, const BF& bf) {
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) {
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[ni].x, acc[0][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.v[ni].y, acc[0][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.v[ni].z, acc[0][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[ni].w, acc[0][ni], 0, 0, 0);
-        }
+        for (int ni = 0; ni < NW; ++ni) acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.v[ni].x, acc[0][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.v[ni].y, acc[0][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.v[ni].z, acc[0][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.v[ni].w, acc[0][ni], 0, 0, 0);
     };
 
     // One K step (32 channels x 1 tap): 16*NW MFMAs per wave in 4 groups of 8 channels.  Software pipeline,
@@ -812,17 +815,19 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
         const int nxt = min(slab + 1, NS - 1);
         if constexpr (kB) { aA = load_a(nxt); bA = load_b(nxt); }
         else { aB = load_a(nxt); bB = load_b(nxt); }
+        // consecutive MFMAs go to different accumulators (the pinned schedule keeps program order)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            const float4 af = kB ? aB.v[g] : aA.v[g];
 #pragma unroll
-            for (int ni = 0; ni < NW; ++ni) {
-                const float4 af = kB ? aB.v[g] : aA.v[g];
-                const float4 bf = kB ? bB.v[g][ni] : bA.v[g][ni];
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[ni], 0, 0, 0);
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[ni], 0, 0, 0);
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[ni], 0, 0, 0);
-                acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[ni], 0, 0, 0);
-            }
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, (kB ? bB.v[g][ni] : bA.v[g][ni]).x, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, (kB ? bB.v[g][ni] : bA.v[g][ni]).y, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, (kB ? bB.v[g][ni] : bA.v[g][ni]).z, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, (kB ? bB.v[g][ni] : bA.v[g][ni]).w, acc[ni], 0, 0, 0);
+        }
         // pinned schedule: the 4 + 4*NW prefetch loads are spread through the MFMA stream (one per PER MFMAs),
         // so each is issued in the shadow of a running MFMA; issued as one burst at the top of the step they
         // cost 16 TA cycles each with the matrix pipe idle (71.8 vs 67.6 ticks per MFMA)
