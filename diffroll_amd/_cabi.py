@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 4
+DR_ABI_VERSION = 5
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
 
 SAMPLERS = {
@@ -27,12 +27,13 @@ SAMPLERS = {
 }
 COND_SPEC, COND_UNCOND = 0, 1
 PRECISIONS = {"f32": 0, "bf16x3": 1}
+NORM_MODES = {"imagewise": 0, "framewise": 1}
 
 # every symbol include/diffroll_amd.h declares
 EXPORTS = [
     "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
     "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
-    "dr_extract_x0", "dr_set_precision", "dr_profile_enable",
+    "dr_extract_x0", "dr_set_spec_norm", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
 ]
 
@@ -93,6 +94,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     for fn in (lib.dr_q_sample, lib.dr_extract_x0):
         fn.restype = C.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp]
+    lib.dr_set_spec_norm.restype = C.c_int
+    lib.dr_set_spec_norm.argtypes = [vp, C.c_int]
     lib.dr_set_precision.restype = C.c_int
     lib.dr_set_precision.argtypes = [vp, C.c_int]
     lib.dr_profile_enable.restype = C.c_int

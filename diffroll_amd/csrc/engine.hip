@@ -77,6 +77,7 @@ struct dr_engine {
     float* xwork = nullptr;                // the captured chain runs in place on this engine-owned roll buffer
     float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
     int prec = 0;                          // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3, 6 products)
+    int norm_framewise = 0;                // spectrogram normalisation: 0 imagewise, 1 framewise (norm_args[2])
     // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
     int fe_B = 0, fe_T = 0;
     size_t cond_cap = 0;
@@ -897,7 +898,8 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     if ((size_t)B * bp * TF > e->fe_cap_pow) { if ((rc = dev_alloc(e, &e->power, (size_t)B * bp * TF))) return rc; e->fe_cap_pow = (size_t)B * bp * TF; }
     if ((size_t)B * mel_planes * 4 * TF > e->fe_cap_log) { if ((rc = dev_alloc(e, &e->logmel, (size_t)B * mel_planes * 4 * TF))) return rc; e->fe_cap_log = (size_t)B * mel_planes * 4 * TF; }
     if ((size_t)B * mel_planes * 4 * T > e->fe_cap_spec) { if ((rc = dev_alloc(e, &e->specP4, (size_t)B * mel_planes * 4 * T))) return rc; e->fe_cap_spec = (size_t)B * mel_planes * 4 * T; }
-    if ((size_t)B * 2 > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, (size_t)B * 2))) return rc; e->fe_cap_mm = (size_t)B * 2; }
+    const size_t mm_need = e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2;
+    if (mm_need > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, mm_need))) return rc; e->fe_cap_mm = mm_need; }
     const size_t cond_need = (size_t)e->L * B * 2 * Cp * T;
     bool cond_moved = false;
     if (cond_need > e->cond_cap) { if ((rc = dev_alloc(e, &e->cond, cond_need))) return rc; e->cond_cap = cond_need; cond_moved = true; }
@@ -928,9 +930,10 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
         HIPCHK(e, launch_gemm(a, EPI_LOG, 2, st));
     }
     // 4. imagewise min-max over the untrimmed TF frames, mask, trim
-    HIPCHK(e, launch_minmax(e->logmel, e->mm, B, mel_planes, TF, NM, st));
+    if (e->norm_framewise) HIPCHK(e, launch_minmax_frame(e->logmel, e->mm, B, mel_planes, TF, NM, st));
+    else HIPCHK(e, launch_minmax(e->logmel, e->mm, B, mel_planes, TF, NM, st));
     HIPCHK(e, launch_normalize(e->logmel, e->mm, e->specP4, d_spec_out, B, mel_planes, mel_planes, TF, T, NM,
-                               mask_t0, mask_t1, mask_f0, mask_f1, st));
+                               mask_t0, mask_t1, mask_f0, mask_f1, st, e->norm_framewise));
     // 5. hoisted conditioner projections, one (B, 2C, T) tensor per layer (model/diffwave.py:143)
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
@@ -1184,6 +1187,13 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     a.dbg = e->dbg_ticks;
     allow_splitk(e, a);
     HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, pick_pointwise_tile(Cp / 64, NB, T, e->prec), (hipStream_t)stream, e->prec));
+    return DR_OK;
+}
+
+int dr_set_spec_norm(dr_engine* e, int mode) {
+    if (!e) return DR_EINVAL;
+    if (mode != DR_NORM_IMAGEWISE && mode != DR_NORM_FRAMEWISE) return fail(e, DR_EINVAL, "unknown normalisation mode %d", mode);
+    e->norm_framewise = mode == DR_NORM_FRAMEWISE;
     return DR_OK;
 }
 

@@ -127,9 +127,11 @@ hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pa
 // per-sample min/max of logmel P4 [B][planes][TF][4] over rows < n_rows -> mm[B][2]
 hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
 // normalise, mask, trim -> spec P4 [B][planes_out][T][4] (rows >= n_rows zero) and optional plain (B, n_rows, T)
+// framewise = 1: mm holds one (min, max) per (sample, frame) [B][TF][2] (launch_minmax_frame) instead of per sample
+hipError_t launch_minmax_frame(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
 hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4, float* spec_plain,
                             int B, int planes_in, int planes_out, int TF, int T, int n_rows,
-                            int mt0, int mt1, int mf0, int mf1, hipStream_t s);
+                            int mt0, int mt1, int mf0, int mf1, hipStream_t s, int framewise = 0);
 hipError_t launch_fill(float* p, float v, long n, hipStream_t s);
 // q_sample / extract_x0 of task/diffusion.py:31-64 (mode 0 / 1): per-sample schedule lookup by t[b], elementwise
 hipError_t launch_noise_mix(int mode, const float* x, const float* y, const int64_t* t, const float* sac,

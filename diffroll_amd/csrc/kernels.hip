@@ -1517,6 +1517,32 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x
     }
 }
 
+// 'framewise' normalisation (model/utils.py:11-19): min / max over the n_rows frequency bins of every frame;
+// one thread per (sample, frame), lanes walk consecutive frames (coalesced float4 per plane)
+__global__ __launch_bounds__(256) void minmax_frame_kernel(const float* __restrict__ x, float* __restrict__ mm,
+                                                           int planes, int TF, int n_rows) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= TF) return;
+    const float4* xb = reinterpret_cast<const float4*>(x) + (long)b * planes * TF + t;
+    float mn = INFINITY, mx = -INFINITY;
+    const int vplanes = (n_rows + 3) >> 2;
+    for (int pl = 0; pl < vplanes; ++pl) {
+        const float4 v = xb[(long)pl * TF];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pl * 4 + e < n_rows) { mn = fminf(mn, vv[e]); mx = fmaxf(mx, vv[e]); }
+    }
+    mm[((long)b * TF + t) * 2 + 0] = mn;
+    mm[((long)b * TF + t) * 2 + 1] = mx;
+}
+hipError_t launch_minmax_frame(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_frame_kernel, dim3((unsigned)((TF + 255) / 256), (unsigned)B), dim3(256), 0, s, logmel, mm,
+                       planes, TF, n_rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s) {
     hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)B), dim3(256), 0, s, logmel, mm, planes, TF, n_rows);
     return hipGetLastError();
@@ -1527,12 +1553,14 @@ hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int 
 __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, const float* __restrict__ mm,
                                                         float* __restrict__ specP4, float* __restrict__ plain,
                                                         int planes_in, int planes_out, int TF, int T, int n_rows,
-                                                        int mt0, int mt1, int mf0, int mf1) {
+                                                        int mt0, int mt1, int mf0, int mf1, int framewise) {
 #pragma clang fp contract(off)
     const int b = blockIdx.z, pl = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
-    const float mn = mm[b * 2], mx = mm[b * 2 + 1];
+    // imagewise: one (min, max) per sample; framewise: one per (sample, frame)
+    const long mi = framewise ? ((long)b * TF + t) * 2 : (long)b * 2;
+    const float mn = mm[mi], mx = mm[mi + 1];
     float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (pl * 4 < n_rows) {
         const float4 v = reinterpret_cast<const float4*>(x)[((long)b * planes_in + pl) * TF + t];
@@ -1557,10 +1585,10 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 
 hipError_t launch_normalize(const float* logmel, const float* mm, float* specP4, float* spec_plain, int B,
                             int planes_in, int planes_out, int TF, int T, int n_rows, int mt0, int mt1, int mf0,
-                            int mf1, hipStream_t s) {
+                            int mf1, hipStream_t s, int framewise) {
     hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)planes_out, (unsigned)B),
                        dim3(256), 0, s, logmel, mm, specP4, spec_plain, planes_in, planes_out, TF, T, n_rows, mt0,
-                       mt1, mf0, mf1);
+                       mt1, mf0, mf1, framewise);
     return hipGetLastError();
 }
 

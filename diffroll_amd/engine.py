@@ -39,7 +39,8 @@ class Engine:
                  dilation_base: int, dilation_bound: int, n_mels: int, timesteps: int,
                  beta_start: float, beta_end: float, sample_rate: int = 16000, n_fft: int = 2048,
                  hop_length: int = 512, f_min: float = 0.0, f_max: float = 8000.0,
-                 device: Optional[torch.device] = None, betas: Optional[torch.Tensor] = None):
+                 device: Optional[torch.device] = None, betas: Optional[torch.Tensor] = None,
+                 norm_mode: str = "imagewise"):
         """betas: optional (timesteps,) schedule replacing linspace(beta_start, beta_end) (diffroll_amd.schedule)."""
         if not torch.cuda.is_available():
             raise EngineError("no ROCm device visible: diffroll_amd runs only on an MI355X (no CPU fallback)")
@@ -62,6 +63,9 @@ class Engine:
         if rc != 0:
             raise EngineError(f"dr_create failed ({rc}): {self.lib.dr_last_error(None).decode()}")
         self.h = h
+        if norm_mode not in _cabi.NORM_MODES:
+            raise ValueError(f"unknown spectrogram normalisation '{norm_mode}'")
+        self._check(self.lib.dr_set_spec_norm(self.h, _cabi.NORM_MODES[norm_mode]))
         self.schedule = make_schedule(beta_start, beta_end, timesteps, betas)
         self._tables = (build_embedding(timesteps).contiguous().float(),
                         sampler_coef_tables(self.schedule).contiguous())

@@ -116,6 +116,8 @@ class ClassifierFreeDiffRoll(nn.Module):
             raise NotImplementedError("unconditional=True cannot run in the reference either: forward() still passes the "
                                       "spectrogram to blocks built without a conditioner and trips the assertion at "
                                       "model/diffwave.py:135-136")
+        if len(norm_args) < 3 or norm_args[2] not in ("imagewise", "framewise"):
+            raise ValueError(f"norm_args[2] must be 'imagewise' or 'framewise' (model/utils.py:10-35), got {norm_args!r}")
         sampling = _attr(sampling if sampling is not None else {"type": "cfdg_ddpm_x0", "w": 0.0})
         training = _attr(training if training is not None else {"mode": "x_0"})
         spec_args = _attr(dict(spec_args))
@@ -182,7 +184,8 @@ class ClassifierFreeDiffRoll(nn.Module):
     @property
     def engine(self) -> Engine:
         if self._engine is None:
-            self._engine = Engine(device=self._device, betas=self._betas(), **self._engine_kwargs)
+            self._engine = Engine(device=self._device, betas=self._betas(), norm_mode=str(self.hparams.norm_args[2]),
+                                  **self._engine_kwargs)
             self._dirty = True
         if self._dirty:
             self._engine.load_params({k: v for k, v in self.state_dict().items()})

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 4
+#define DR_ABI_VERSION 5
 
 enum {
     DR_OK = 0,
@@ -217,6 +217,13 @@ int dr_q_sample(dr_engine* e, const float* d_x_start, const float* d_noise, cons
 int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, const int64_t* d_t,
                   const float* d_sac, const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out,
                   void* stream);
+
+/* Spectrogram normalisation of the following dr_frontend calls: the mode of Normalization(0, 1, norm_args[2])
+ * (model/diffwave.py:632, model/utils.py:10-32) - min-max per clip ("imagewise", the default and the released
+ * configs) or per frame over the frequency bins ("framewise"). */
+#define DR_NORM_IMAGEWISE 0
+#define DR_NORM_FRAMEWISE 1
+int dr_set_spec_norm(dr_engine* e, int mode);
 
 /* Select DR_PRECISION_* for subsequent dr_forward / dr_step / dr_sample calls (default F32).
  * Drops a captured chain. */

@@ -179,6 +179,16 @@ def normalize_imagewise(x: Tensor, lo: float = 0.0, hi: float = 1.0) -> Tensor:
     return x_scaled
 
 
+def normalize_framewise(x: Tensor, lo: float = 0.0, hi: float = 1.0) -> Tensor:
+    """model/utils.py:11-19: min-max over the frequency axis of every frame of (B, F, T); NaN (constant frame)
+    -> 0 BEFORE the affine map."""
+    x_max = x.max(1, keepdim=True)[0]
+    x_min = x.min(1, keepdim=True)[0]
+    x_std = (x - x_min) / (x_max - x_min)
+    x_std[torch.isnan(x_std)] = 0
+    return x_std * (hi - lo) + lo
+
+
 def frontend(waveform: Tensor, hp: dict, T_roll: int, sampling: bool = False,
              inpainting_t: Optional[Sequence[int]] = None,
              inpainting_f: Optional[Sequence[int]] = None) -> Tensor:
@@ -186,7 +196,10 @@ def frontend(waveform: Tensor, hp: dict, T_roll: int, sampling: bool = False,
     -> (sampling=True: all -1) -> trim to min(T_roll, T_spec).  Returns (B, n_mels, T)."""
     spec = mel_spectrogram(waveform, hp)
     spec = torch.log(spec + 1e-6)
-    spec = normalize_imagewise(spec, 0.0, 1.0)
+    if hp.get("norm_mode", "imagewise") == "framewise":        # norm_args[2], model/diffwave.py:632
+        spec = normalize_framewise(spec, 0.0, 1.0)
+    else:
+        spec = normalize_imagewise(spec, 0.0, 1.0)
     if inpainting_t and inpainting_f is None:
         spec[:, :, int(inpainting_t[0]):int(inpainting_t[1])] = -1
     elif inpainting_t is None and inpainting_f:

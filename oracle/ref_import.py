@@ -152,7 +152,7 @@ def build_reference(hp: dict, sampler: str, w: float = 0.0, inpainting_t=None, i
     with contextlib.redirect_stderr(io.StringIO()):
         m = ref_model.ClassifierFreeDiffRoll(
             residual_channels=hp["residual_channels"], unconditional=False, condition=hp.get("condition", "fixed"),
-            n_mels=hp["n_mels"], norm_args=[0, 1, "imagewise"],
+            n_mels=hp["n_mels"], norm_args=[0, 1, hp.get("norm_mode", "imagewise")],
             residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
             dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
             spec_args=spec_args, spec_dropout=0.1, inpainting_t=inpainting_t,

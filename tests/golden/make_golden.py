@@ -197,6 +197,28 @@ def gen_notes():
     save("notes", n=len(rolls), **out)
 
 
+def gen_framewise():
+    """norm_args[2] = 'framewise' (model/utils.py:11-19): per-frame min-max of the log-mel; front-end outputs and one
+    conditional evaluation from the reference."""
+    hp = hp_small(3)
+    hp["norm_mode"] = "framewise"
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5)
+    params = R.synthetic_params(hp, seed=12)
+    RI.load_params(m, params)
+    torch.manual_seed(91)
+    L = 16 * 512
+    T = 16
+    n = torch.arange(L, dtype=torch.float64)
+    wav = torch.cat([0.1 * torch.randn(2, L), (0.5 * torch.sin(2 * np.pi * 440.0 * n / 16000.0)).float()[None],
+                     torch.zeros(1, L)], 0)
+    x = torch.randn(4, 1, T, 88)
+    t = torch.tensor(3).repeat(4)
+    with torch.no_grad():
+        x0, spec = m(x, wav, t)
+        _, spec_t = m(x, wav, t, inpainting_t=[4, 9])
+    save("framewise", hp=json.dumps(hp), seed=12, wsum=weight_checksum(params), wav=wav, x=x, T=T, spec=spec, spec_t=spec_t, x0=x0)
+
+
 def gen_forward_steps():
     """forward() with one diffusion step PER SAMPLE, as step() calls it (task/diffusion.py:677-690)."""
     hp = hp_small(9, C=32, L=5, S=8)
@@ -295,6 +317,9 @@ if __name__ == "__main__":
     if "--steps-only" in sys.argv:
         gen_forward_steps()
         sys.exit(0)
+    if "--framewise-only" in sys.argv:
+        gen_framewise()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
@@ -305,3 +330,4 @@ if __name__ == "__main__":
     gen_beta_schedules()
     gen_trainable_spec()
     gen_forward_steps()
+    gen_framewise()

@@ -594,6 +594,31 @@ def test_forward_with_per_sample_steps_golden(golden_dir):
         assert maxdiff(out.cpu(), ref) <= ATOL_FWD, precision
 
 
+def test_framewise_normalisation_golden(golden_dir):
+    """norm_args[2] = 'framewise' (model/utils.py:11-19: per-frame min-max over the mel bins, NaN -> 0) vs the
+    reference run on random, sine and silent clips, with and without an inpainting mask."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    g = np.load(os.path.join(golden_dir, "framewise.npz"))
+    hp = json.loads(str(g["hp"]))
+    p = R.synthetic_params(hp, seed=int(g["seed"]))
+    kw = dict(residual_channels=hp["residual_channels"], unconditional=False, condition="fixed", n_mels=hp["n_mels"],
+              norm_args=[0, 1, "framewise"], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
+              dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
+              spec_args=dict(sample_rate=16000, n_fft=hp["n_fft"], hop_length=hp["hop_length"], n_mels=hp["n_mels"], f_min=0,
+                             f_max=8000), timesteps=hp["timesteps"], training={"mode": "x_0"},
+              sampling={"type": "cfdg_ddpm_x0", "w": 0.5})
+    m = ClassifierFreeDiffRoll(**kw)
+    m.load_state_dict(p)
+    t = torch.tensor(3).repeat(4)
+    x0, spec = m(T(g["x"]), T(g["wav"]), t)
+    assert maxdiff(spec.cpu(), T(g["spec"])) <= ATOL_SPEC
+    assert maxdiff(x0.cpu(), T(g["x0"])) <= ATOL_FWD
+    _, spec_t = m(T(g["x"]), T(g["wav"]), t, inpainting_t=[4, 9])
+    assert maxdiff(spec_t.cpu(), T(g["spec_t"])) <= ATOL_SPEC
+    with pytest.raises(ValueError):
+        ClassifierFreeDiffRoll(**{**kw, "norm_args": [0, 1, "freqwise"]})
+
+
 def test_trainable_spec_condition_golden(golden_dir):
     """condition='trainable_spec' (model/diffwave.py:600-606, :656-658): the unconditional branch reads the learned
     (n_mels, 641) spectrogram through every layer's conditioner (hoisted like the clip's); forward(sampling=True),

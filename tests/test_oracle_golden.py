@@ -164,3 +164,16 @@ def test_forward_with_per_sample_steps(golden_dir):
         x0_u, _ = R.forward(p, hp, T_("x"), torch.zeros_like(T_("wav")), T_("t"), sampling=True)
     assert float((x0_c - T_("x0_c")).abs().max()) <= 2e-5
     assert float((x0_u - T_("x0_u")).abs().max()) <= 2e-5
+
+
+def test_framewise_normalisation(golden_dir):
+    """norm_args[2] = 'framewise' (model/utils.py:11-19) vs the reference run (random, sine and silent clips)."""
+    g = np.load(os.path.join(golden_dir, "framewise.npz"))
+    hp = json.loads(str(g["hp"]))
+    p = R.synthetic_params(hp, seed=int(g["seed"]))
+    T_ = lambda k: torch.from_numpy(np.asarray(g[k]))
+    with torch.no_grad():
+        x0, spec = R.forward(p, hp, T_("x"), T_("wav"), torch.tensor(3).repeat(4))
+        spec_t = R.frontend(T_("wav"), hp, int(g["T"]), inpainting_t=[4, 9])
+    assert float((spec - T_("spec")).abs().max()) <= 2e-5 and float((spec_t - T_("spec_t")).abs().max()) <= 2e-5
+    assert float((x0 - T_("x0")).abs().max()) <= 2e-5
