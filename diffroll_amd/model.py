@@ -162,6 +162,21 @@ class ClassifierFreeDiffRoll(nn.Module):
                 raise NotImplementedError(f"spec_args.{key}=False is not supported (config/spec/mel.yaml)")
         if sa.get("pad_mode", "reflect") != "reflect":
             raise NotImplementedError("only pad_mode='reflect' is supported (config/spec/mel.yaml)")
+        # every other torchaudio MelSpectrogram argument must be at the value the front-end kernels implement
+        # (torchaudio 0.11 defaults) - nothing is silently ignored
+        fixed = {"win_length": (None, int(sa.get("n_fft", 2048))), "power": (2.0, 2), "mel_scale": ("htk",),
+                 "norm": (None,), "onesided": (True,), "pad": (0,), "window_fn": (torch.hann_window,),
+                 "wkwargs": (None,)}
+        known = {"sample_rate", "n_fft", "hop_length", "n_mels", "f_min", "f_max", "center", "normalized", "pad_mode"}
+        for key, val in sa.items():
+            if key in known:
+                continue
+            if key not in fixed:
+                raise TypeError(f"spec_args: unknown MelSpectrogram argument '{key}'")
+            if val not in fixed[key]:
+                raise NotImplementedError(f"spec_args.{key}={val!r} is not supported (front-end implements {fixed[key][0]!r})")
+        if int(sa.get("n_mels", n_mels)) != int(n_mels):
+            raise ValueError(f"spec_args.n_mels={sa.get('n_mels')} differs from n_mels={n_mels} (the conditioner's input width)")
         self._device = device
         self.precision = precision          # 'f32' (exact, default) | 'bf16x3' (opt-in split precision)
         self._engine: Optional[Engine] = None

@@ -307,3 +307,31 @@ def test_extra_beta_schedules_bit_equal(golden_dir):
     assert torch.equal(sch["betas"], torch.from_numpy(g["cosine_50"]))
     tab = S.posterior_coef_table(sch)
     assert tab.shape == (50, 5) and bool(torch.isfinite(tab).all())
+
+
+def test_facade_rejects_unsupported_front_end_options():
+    """Nothing the kernels do not implement is silently ignored: MelSpectrogram arguments off their implemented
+    values, an unknown normalisation mode or mismatching n_mels raise at construction."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+
+    def make(spec_extra=None, **kw):
+        sa = dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000, center=True,
+                  normalized=True, pad_mode="reflect")
+        sa.update(spec_extra or {})
+        args = dict(residual_channels=64, unconditional=False, condition="fixed", n_mels=229, norm_args=[0, 1, "imagewise"],
+                    residual_layers=2, kernel_size=3, spec_args=sa)
+        args.update(kw)
+        return ClassifierFreeDiffRoll(**args)
+
+    make()
+    make({"power": 2.0, "win_length": 2048, "mel_scale": "htk"})
+    for bad in ({"power": 1.0}, {"win_length": 1024}, {"mel_scale": "slaney"}, {"norm": "slaney"}, {"center": False},
+                {"pad_mode": "constant"}):
+        with pytest.raises(NotImplementedError):
+            make(bad)
+    with pytest.raises(TypeError):
+        make({"not_an_argument": 1})
+    with pytest.raises(ValueError):
+        make({"n_mels": 128})
+    with pytest.raises(ValueError):
+        make(norm_args=[0, 1, "freqwise"])
