@@ -490,6 +490,9 @@ class ClassifierFreeDiffRoll(nn.Module):
 
     def sampling(self, batch, batch_idx=0):
         """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""
+        if self.hparams.debug:
+            raise NotImplementedError("debug=True feeds the label roll where the waveform belongs "
+                                      "(task/diffusion.py:780-781): a development switch of the reference, not a mode")
         frame = batch["frame"]
         x_T = torch.randn(frame.shape[0], 1, frame.shape[1], frame.shape[2], device=self.engine.device)
         return self.sample(x_T, batch["audio"], seed=batch_idx)
