@@ -321,6 +321,38 @@ def test_sample_trajectory_matches_chain(golden_dir):
     assert torch.equal(traj[-1], roll)
 
 
+def test_load_from_checkpoint_end_to_end(tmp_path):
+    """A Lightning-shaped checkpoint ({'state_dict', 'hyper_parameters'} incl. the mel buffers and the
+    non-persistent embedding a real one may carry) -> load_from_checkpoint(path, **overrides) (sampling.py:54-65)
+    -> the same roll as a model built directly; the k=9 override of README.md:39 goes through the kwargs."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=3, kernel_size=9, timesteps=6)
+    p = R.synthetic_params(hp, seed=77)
+    sd = dict(p)
+    sd["mel_layer.spectrogram.window"] = torch.hann_window(2048)
+    sd["mel_layer.mel_scale.fb"] = torch.zeros(1025, 229)
+    hyper = dict(residual_channels=64, unconditional=False, condition="fixed", n_mels=229, norm_args=[0, 1, "imagewise"],
+                 residual_layers=3, kernel_size=3, dilation_base=2, dilation_bound=4, spec_dropout=0.1,
+                 spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000, center=True,
+                                normalized=True, pad_mode="reflect"),
+                 lr=1e-4, timesteps=6, loss_type="l2", loss_keys=["diffusion_loss"], beta_start=1e-4, beta_end=0.02,
+                 frame_threshold=0.5, training={"mode": "x_0"}, sampling={"type": "ddpm_x0"}, debug=False,
+                 generation_filter=0.02, inpainting_t=None, inpainting_f=None)
+    path = tmp_path / "model.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hyper, "epoch": 3, "pytorch-lightning_version": "1.6.4"}, path)
+    m = ClassifierFreeDiffRoll.load_from_checkpoint(str(path), kernel_size=9, sampling={"type": "cfdg_ddpm_x0", "w": 0.5})
+    assert m.hparams.kernel_size == 9 and m.hparams.sampling.type == "cfdg_ddpm_x0"
+    ref = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    torch.manual_seed(1)
+    wav = 0.1 * torch.randn(2, 40 * 512)
+    x = torch.randn(2, 1, 40, 88)
+    nz = torch.randn(6, 2, 1, 40, 88)
+    a, _ = m.sample(x, wav, noise=nz)
+    b, _ = ref.sample(x, wav, noise=nz)
+    assert torch.equal(a, b)
+
+
 def test_cli_drivers_end_to_end(tmp_path):
     """The sampling.py / infer.py command surface (diffroll_amd/cli.py) on the GPU: wav folder in (Custom dataset,
     utils/custom_dataset.py:55-91), rolls + raw / clean MIDI out, for the three tasks' samplers."""
