@@ -71,7 +71,7 @@ struct dr_engine {
     int ws_NB = 0, ws_T = 0;
     // split-K workspace (partials) and ticket counters, see gemm_kernel
     float* sk_ws = nullptr;
-    float* sk_cnt = nullptr;
+    unsigned* sk_cnt = nullptr;
     static constexpr size_t SK_WS_FLOATS = (size_t)8 << 20, SK_CNT_N = 4096;
     float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
     float* xwork = nullptr;                // the captured chain runs in place on this engine-owned roll buffer
@@ -351,17 +351,25 @@ Tile pick_pointwise_tile(int MT, int NB, int T, int prec) {
 }
 // let the launcher split K when the launch under-fills the chip (single clips, narrow projections)
 void allow_splitk(const dr_engine* e, GemmArgs& a) {
-    a.ws = e->sk_ws; a.ws_cnt = reinterpret_cast<unsigned*>(e->sk_cnt);
+    a.ws = e->sk_ws; a.ws_cnt = e->sk_cnt;
     a.ws_floats = dr_engine::SK_WS_FLOATS; a.ws_cnt_n = dr_engine::SK_CNT_N;
 }
 
 // common GemmArgs for a P4 activation input [NB][planes][T][4]
-const float* g_zero_vec = nullptr;   // device zero vector shared by every engine of the process
+// Device zero vector (a never-null bias / d2 operand: epilogue loads are unconditional), one per device, shared by
+// the engines of the process on that device and never freed.
+constexpr int MAX_DEVICES = 64;
+const float* g_zero_vecs[MAX_DEVICES] = {};
+const float* zero_vec() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return (dev >= 0 && dev < MAX_DEVICES) ? g_zero_vecs[dev] : nullptr;
+}
 
 GemmArgs p4_gemm(const float* Wp, const float* bias, int MT, const float* X, int planes, int NB, int T) {
     GemmArgs a{};
-    a.d2 = g_zero_vec;
-    a.Wp = Wp; a.bias = bias ? bias : g_zero_vec; a.MT = MT;
+    a.d2 = zero_vec();
+    a.Wp = Wp; a.bias = bias ? bias : zero_vec(); a.MT = MT;
     a.X = X; a.x_bs = (long)planes * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4; a.x_planes = planes;
     a.kchunks = (planes + 7) / 8;
     a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
@@ -597,12 +605,13 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
         hipError_t ie = init_kernels();
         if (ie != hipSuccess) return fail(nullptr, DR_EHIP, "kernel init failed: %s", hipGetErrorString(ie));
     }
-    if (!g_zero_vec) {
+    if (cfg->device >= MAX_DEVICES) return fail(nullptr, DR_EINVAL, "device %d out of range", cfg->device);
+    if (!g_zero_vecs[cfg->device]) {
         void* z = nullptr;
         const size_t zn = 1 << 16;   // floats; covers every Cin on the path (n_fft, bins, channels)
         if (hipMalloc(&z, zn * sizeof(float)) != hipSuccess || hipMemset(z, 0, zn * sizeof(float)) != hipSuccess)
             return fail(nullptr, DR_EHIP, "allocating the zero vector failed");
-        g_zero_vec = (const float*)z;
+        g_zero_vecs[cfg->device] = (const float*)z;
     }
     if (cfg->n_fft > (1 << 16) || cfg->residual_channels > (1 << 15))
         return fail(nullptr, DR_EINVAL, "configuration too large");
@@ -641,11 +650,12 @@ void dr_destroy(dr_engine* e) {
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
+    if (e->sk_cnt) (void)hipFree(e->sk_cnt);
     if (e->d_tsel) (void)hipFree(e->d_tsel);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
-                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->sk_cnt, e->xwork, e->cond_tr};
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->xwork, e->cond_tr};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -830,7 +840,12 @@ int dr_commit(dr_engine* e, void* stream) {
     HIPCHK(e, hipMemcpy(e->d_coef, e->h_coef.data(), (size_t)DR_COEF_FAMILIES * S * 5 * sizeof(float), hipMemcpyHostToDevice));
     if ((rc = dev_alloc(e, &e->d_dtab, (size_t)S * L * Cp))) return rc;
     if ((rc = dev_alloc(e, &e->sk_ws, dr_engine::SK_WS_FLOATS, false))) return rc;
-    if ((rc = dev_alloc(e, &e->sk_cnt, dr_engine::SK_CNT_N))) return rc;
+    if (!e->sk_cnt) {       // ticket counters: zero between launches (the kernels re-arm them)
+        void* q = nullptr;
+        HIPCHK(e, hipMalloc(&q, dr_engine::SK_CNT_N * sizeof(unsigned)));
+        HIPCHK(e, hipMemset(q, 0, dr_engine::SK_CNT_N * sizeof(unsigned)));
+        e->sk_cnt = (unsigned*)q;
+    }
     if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by
@@ -916,10 +931,10 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     //    (plane stride 4 samples, frame stride hop) - no im2col copy.
     {
         GemmArgs a{};
-        a.Wp = e->dft_w; a.MT = bp / 64; a.bias = g_zero_vec;
+        a.Wp = e->dft_w; a.MT = bp / 64; a.bias = zero_vec();
         a.X = e->wav_pad; a.x_bs = Lp; a.x_ps = 4; a.x_fs = hop; a.x_planes = N / 4; a.kchunks = N / 32;
         a.NB = B; a.T = TF; a.taps = 1; a.dil = 1; a.alpha = 1.f;
-        a.d2 = g_zero_vec;
+        a.d2 = zero_vec();
         p4_out(a, e->power, bp / 4, TF, bp);
         HIPCHK(e, launch_gemm(a, EPI_POWER, 2, st));
     }
@@ -1126,6 +1141,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     if (layer < 0 || layer >= e->L || t < 0 || t >= e->S || n_cond < 0 || n_cond > NB)
         return fail(e, DR_EINVAL, "bad argument");
     if (n_cond > 0 && (e->fe_B < n_cond || e->fe_T != T)) return fail(e, DR_ESTATE, "dr_frontend needed for n_cond > 0");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
     int rc = ensure_workspace(e, NB, T);
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
@@ -1160,6 +1176,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     if (!e) return DR_EINVAL;
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (layer < 0 || layer >= e->L) return fail(e, DR_EINVAL, "bad argument");
+    HIPCHK(e, hipSetDevice(e->cfg.device));
     int rc = ensure_workspace(e, NB, T);
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
