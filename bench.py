@@ -95,13 +95,33 @@ def cpu_baseline(model, budget_s=12.0, max_steps=6):
             x = R.reverse_step(params, hp, sch, SAMPLER, x, spec, t_index, z, W_CFG, table)
             n += 1
         t_steps = time.perf_counter() - t0
+        # BASELINE.md section 3 also asks for the single-thread figure: one reverse step of ONE clip, scaled to the
+        # batch (the per-clip work is independent), extrapolated like the multi-thread figure
+        torch.set_num_threads(1)
+        try:
+            t0 = time.perf_counter()
+            R.reverse_step(params, hp, sch, SAMPLER, x[:1], spec[:1], hp["timesteps"] - 1, z[:1], W_CFG, table)
+            t_one = time.perf_counter() - t0
+        finally:
+            torch.set_num_threads(cores)
     per_step = t_steps / n
     total = t_front + per_step * hp["timesteps"]
+    model_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": round(B_LOCAL * T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
         "sample": f"{n} of 200 reverse steps (2 network evaluations each) at B={B_LOCAL},T={T} + one front-end, "
                   f"{t_steps + t_front:.1f} s of CPU work, extrapolated to the 200-step chain",
-        "os_cpu_count": os.cpu_count(), "s_per_step": round(per_step, 4),
+        "os_cpu_count": os.cpu_count(), "cpu_model": model_name, "s_per_step": round(per_step, 4),
+        "single_thread": {"value": round(T / (t_one * hp["timesteps"]), 3), "unit": "frames/s", "cores": 1,
+                          "sample": f"1 reverse step of 1 clip ({t_one:.1f} s), extrapolated to 200 steps"},
     }
 
 
