@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the oracle is torch-CPU: torch's default thread count inside the GPU box's container (128) is ~8x slower than
+    # 16 for these shapes (bench.py cpu_baseline measures it) - cap it so the parity suite spends its time on the GPU
+    import torch
+    torch.set_num_threads(min(16, torch.get_num_threads()))
 
 
 @pytest.fixture(scope="session")

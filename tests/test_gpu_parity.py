@@ -283,6 +283,7 @@ def test_batch_shard_bitwise_without_splitk():
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, torch
+        torch.set_num_threads(min(16, torch.get_num_threads()))
         sys.path.insert(0, %r)
         from oracle import diffroll_ref as R
         from tests.test_gpu_parity import make_model, _cfg2_inputs
@@ -805,6 +806,7 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
     # the tile override is read once per process: run each forced variant in a child process
     code = textwrap.dedent("""
         import sys, torch, numpy as np
+        torch.set_num_threads(min(16, torch.get_num_threads()))
         sys.path.insert(0, %r)
         from oracle import diffroll_ref as R
         from tests.test_gpu_parity import make_model
