@@ -42,7 +42,24 @@ def main():
         with torch.cuda.stream(s2):
             mu.sample(x, wav, seed=0)
 
-    print("ddpm_x0 || generation on two streams: %.1f ms" % timed(both))
+    print("ddpm_x0 || generation on two streams, one host thread: %.1f ms" % timed(both))
+
+    # hipGraphLaunch of a 6800-node graph blocks the calling thread for ~half the chain (the queue holds ~4k
+    # packets), so a single host thread launches the second graph late: give each stream its own thread
+    import threading
+
+    def run(model, stream):
+        with torch.cuda.stream(stream):
+            model.sample(x, wav, seed=0)
+
+    def both_threads():
+        ts = [threading.Thread(target=run, args=(mc, s1)), threading.Thread(target=run, args=(mu, s2))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    print("ddpm_x0 || generation on two streams, two host threads: %.1f ms" % timed(both_threads))
 
 
 if __name__ == "__main__":
