@@ -137,7 +137,7 @@ def cpu_baseline(model, budget_s=12.0, max_steps=40):
         "sample": f"{n} of 200 reverse steps (2 network evaluations each) at B={B_LOCAL},T={T} + one front-end, "
                   f"{t_steps + t_front:.1f} s of CPU work, extrapolated to the 200-step chain",
         "os_cpu_count": os.cpu_count(), "cpu_model": model_name, "s_per_step": round(per_step, 4),
-        "threads_note": f"thread count chosen by a short sweep (torch default here: {default_threads})",
+        "threads_note": f"thread count chosen by a short ascending sweep over 4..128 (os.cpu_count() = {os.cpu_count()})",
         "single_thread": {"value": round(T / (t_one * hp["timesteps"]), 3), "unit": "frames/s", "cores": 1,
                           "sample": f"1 reverse step of 1 clip ({t_one:.1f} s), extrapolated to 200 steps"},
     }
@@ -164,6 +164,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # host-side torch ops here are tiny; keep N ranks from each spawning one CPU thread per hardware thread
+    torch.set_num_threads(min(16, torch.get_num_threads()))
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at N = 1)
         import torch.distributed as dist
