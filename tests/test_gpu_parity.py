@@ -231,6 +231,29 @@ def test_config3_generation_steps_vs_oracle(full_model):
     assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
 
 
+def test_full_200_step_guided_chain_vs_oracle(full_model):
+    """The north_star statement itself at full depth: the k=9, C=512, 15-layer network, all 200 reverse steps of
+    cfdg_ddpm_x0 (w=0.5) on 4-s clips with identical injected noise - final roll within the fp32 tolerance of the
+    oracle and the thresholded roll (> 0.5, what frame-F1 is computed from) identical except within 1e-4 of the
+    threshold; in both precisions."""
+    hp, p, _ = full_model
+    torch.manual_seed(200)
+    B, Tn = 2, 125
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    noise = torch.randn(hp["timesteps"], B, 1, Tn, 88)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    near = (ref - 0.5).abs() < 1e-4
+    for precision in ("f32", "bf16x3"):
+        m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, precision=precision)
+        roll, _ = m.sample(x, wav, noise=noise)
+        roll = roll.cpu()
+        d = maxdiff(roll, ref)
+        assert d <= ATOL_STEP, (precision, d)
+        assert bool((((roll > 0.5) == (ref > 0.5)) | near).all()), precision
+
+
 # --------------------------------------------------------------------------------------------
 # size-independent properties at BASELINE config 2 shape (B=16, T=125, k=9, 200 steps)
 # --------------------------------------------------------------------------------------------
