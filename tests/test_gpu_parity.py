@@ -211,6 +211,30 @@ def test_config5_shape_step_vs_oracle():
     assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
 
 
+def test_config5_shape_chain_vs_oracle():
+    """BASELINE config 5 geometry as a chain: k=15 full-size network, one 640-frame clip, the last 12 reverse steps
+    of a 200-step schedule run back to back (inpainting sampler with a masked spectrogram span) vs the oracle."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(kernel_size=15, timesteps=200)
+    p = R.synthetic_params(hp, seed=15)
+    m = make_model(hp, p, sampler="inpainting_ddpm_x0", w=0.5, inpainting_t=[200, 330])
+    torch.manual_seed(6)
+    Tn = 640
+    wav = 0.1 * torch.randn(1, Tn * 512)
+    x = torch.randn(1, 1, Tn, 88)
+    steps = list(range(11, -1, -1))
+    z = torch.randn(len(steps), 1, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], 200)
+    ref, out = x, x
+    with torch.no_grad():
+        spec = R.frontend(wav, hp, Tn, inpainting_t=[200, 330])
+        for i, t in enumerate(steps):
+            ref = R.reverse_step(p, hp, sch, "inpainting_ddpm_x0", ref, spec, t, z[i], 0.5)
+    for i, t in enumerate(steps):
+        out, _ = m.reverse_diffusion(out, wav, t, noise=z[i])
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
 def test_config3_generation_steps_vs_oracle(full_model):
     """BASELINE config 3 per-GPU geometry: unconditional generation (spec == -1), 16 clips of 125 frames - three
     consecutive reverse steps (one evaluation each, 64-frame blocks) against the oracle."""
