@@ -43,8 +43,9 @@ struct GraphKey {
     int sampler = -1, B = 0, T = 0;
     float* x = nullptr;
     const float* noise = nullptr;
+    bool w_zero = false;        // guidance weight 0 captures a different (conditional-only) chain
     bool operator==(const GraphKey& o) const {
-        return sampler == o.sampler && B == o.B && T == o.T && x == o.x && noise == o.noise;
+        return sampler == o.sampler && B == o.B && T == o.T && x == o.x && noise == o.noise && w_zero == o.w_zero;
     }
 };
 
@@ -552,6 +553,9 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
     int NB, n_cond, family;
     bool zero_spec;
     if (sampler_shape(sampler, B, NB, n_cond, family, zero_spec)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
+    // Guidance weight 0: x0 = (1 + 0) c - 0 u = c (task/diffusion.py:953) - the unconditional evaluation is
+    // multiplied by zero, so it is not run (half the work; the w = 0 points of the paper's guidance sweeps).
+    if (w == 0.f && NB == 2 * B) { NB = B; n_cond = B; }
     int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st, zero_spec);
     if (rc) return rc;
     UpdateArgs u{};
@@ -1031,7 +1035,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     }
 
     GraphKey key;
-    key.sampler = sampler; key.B = B; key.T = T; key.x = e->xwork; key.noise = d_noise;
+    key.sampler = sampler; key.B = B; key.T = T; key.x = e->xwork; key.noise = d_noise; key.w_zero = (w == 0.f);
     if (!e->gexec || !(key == e->gkey)) {
         if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
