@@ -912,7 +912,14 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     const int Cp = e->Cp, NM = e->NM, bp = e->bins_p;
     const int mel_planes = (NM + 3) / 4;
     int rc;
-    HIPCHK(e, hipStreamSynchronize(st));   // buffers below may be reallocated
+    {   // buffers below are reallocated only when a shape grows: synchronise just then (a previous call may still
+        // be reading them), not on every call
+        const size_t mm_need0 = e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2;
+        const bool grow = (size_t)B * Lp > e->fe_cap_wav || (size_t)B * bp * TF > e->fe_cap_pow ||
+                          (size_t)B * mel_planes * 4 * TF > e->fe_cap_log || (size_t)B * mel_planes * 4 * T > e->fe_cap_spec ||
+                          mm_need0 > e->fe_cap_mm || (size_t)e->L * B * 2 * Cp * T > e->cond_cap;
+        if (grow) HIPCHK(e, hipDeviceSynchronize());
+    }
     if ((size_t)B * Lp > e->fe_cap_wav) { if ((rc = dev_alloc(e, &e->wav_pad, (size_t)B * Lp))) return rc; e->fe_cap_wav = (size_t)B * Lp; }
     if ((size_t)B * bp * TF > e->fe_cap_pow) { if ((rc = dev_alloc(e, &e->power, (size_t)B * bp * TF))) return rc; e->fe_cap_pow = (size_t)B * bp * TF; }
     if ((size_t)B * mel_planes * 4 * TF > e->fe_cap_log) { if ((rc = dev_alloc(e, &e->logmel, (size_t)B * mel_planes * 4 * TF))) return rc; e->fe_cap_log = (size_t)B * mel_planes * 4 * TF; }
