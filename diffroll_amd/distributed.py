@@ -74,6 +74,9 @@ def sample_sharded(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], n
     z = None if noise is None else noise[:, lo:hi]
     if hi > lo:
         roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
-    else:
-        roll = x_T.new_zeros((0,) + tuple(x_T.shape[1:])).to(model.engine.device)
+    else:       # more ranks than clips: an empty shard with the frame count the other ranks will produce
+        T = x_T.shape[2]
+        if waveform is not None:
+            T = min(T, waveform.shape[-1] // model.engine.hop_length + 1)       # trim_spec_roll, model/diffwave.py:30-39
+        roll = torch.zeros((0, 1, T, x_T.shape[3]), dtype=torch.float32, device=model.engine.device)
     return gather_rolls_uneven(roll, B, group)
