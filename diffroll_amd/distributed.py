@@ -76,7 +76,8 @@ def sample_sharded(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], n
         roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
     else:       # more ranks than clips: an empty shard with the frame count the other ranks will produce
         T = x_T.shape[2]
-        if waveform is not None:
-            T = min(T, waveform.shape[-1] // model.engine.hop_length + 1)       # trim_spec_roll, model/diffwave.py:30-39
+        hop = getattr(model.engine, "hop_length", None)
+        if waveform is not None and hop:
+            T = min(T, waveform.shape[-1] // hop + 1)       # trim_spec_roll, model/diffwave.py:30-39
         roll = torch.zeros((0, 1, T, x_T.shape[3]), dtype=torch.float32, device=model.engine.device)
     return gather_rolls_uneven(roll, B, group)
