@@ -506,8 +506,11 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             // the last layer's residual output is never read (model/diffwave.py:678-682 only uses the skip sum
             // after the loop): launch the skip half of the M tiles only
             if (l + 1 == L && tile.flavor == 2) {
-                const Tile half = pick_pointwise_tile(Cp / 128, NB, T, prec);
-                if (half.flavor == 2) { tile = half; a.MT = Cp / 128; a.mt0 = Cp / 128; }
+                // packed rows [0, Cp) are the residual half: the first 128-row tile holding a skip row is Cp / 128
+                // (when Cp is not a multiple of 128 that tile also recomputes a few residual rows: harmless)
+                const int first = Cp / 128, count = Cp / 64 - first;
+                const Tile half = pick_pointwise_tile(count, NB, T, prec);
+                if (half.flavor == 2) { tile = half; a.MT = count; a.mt0 = first; }
             }
             HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, tile, st, prec));
         }

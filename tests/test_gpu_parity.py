@@ -432,6 +432,25 @@ def test_cli_drivers_end_to_end(tmp_path):
     assert np.isfinite(np.load(out / "rolls_batch0.npy")).all()
 
 
+def test_odd_channel_padding_at_filled_launches():
+    """C = 160 pads to 192 channels = 3 row tiles, so the residual / skip halves of the 1x1 do not fall on tile
+    boundaries; a batch large enough for the direct-operand 1x1 (incl. the last layer's skip-only launch)."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=160, residual_layers=3, kernel_size=9, timesteps=6)
+    p = R.synthetic_params(hp, seed=160)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    torch.manual_seed(16)
+    B, Tn = 40, 125            # 80 evaluations: enough tiles for the skip-only launch of the last layer to be taken
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(B, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], 6)
+    with torch.no_grad():
+        ref = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, R.frontend(wav, hp, Tn), 3, z, 0.5)
+    out, _ = m.reverse_diffusion(x, wav, 3, noise=z)
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
 def test_large_batch_self_consistency(full_model):
     """Far beyond the oracle's reach (96 clips x 640 frames, k=9, guided: 192 evaluations per step, 1280-block
     launches): every clip of the big batch equals the same clip run in a batch of four (independent units,
