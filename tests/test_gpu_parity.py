@@ -702,6 +702,45 @@ def test_random_configurations_vs_oracle():
         assert d <= ATOL_STEP, (case, hp, sampler, w, B, Tn, t, precision, d)
 
 
+def test_random_chains_vs_oracle():
+    """Randomised (fixed seed) whole chains through dr_sample (captured graph) against the oracle's loop: random
+    depth / width / kernel size / schedule length, the four x0-prediction samplers and the DDIM / epsilon ones,
+    both conditioning modes ('fixed', 'trainable_spec'), both spectrogram normalisations, inpainting masks in time
+    and frequency, Tn from 1 frame up, both precisions."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    rng = np.random.default_rng(77)
+    samplers = ["cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0", "ddpm_x0", "ddim_x0", "cfdg_ddim_x0", "ddpm",
+                "ddim", "ddim2ddpm"]
+    for case in range(120):
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=int(rng.choice([32, 64, 96, 128])), residual_layers=int(rng.integers(1, 5)),
+                  kernel_size=int(rng.choice([3, 5, 9, 15])), timesteps=int(rng.integers(2, 7)),
+                  condition=str(rng.choice(["fixed", "trainable_spec"])), norm_mode=str(rng.choice(["imagewise", "framewise"])))
+        sampler = samplers[case % 9]
+        w = float(rng.choice([0.0, 0.5, 2.0]))
+        B, Tn = int(rng.integers(1, 5)), int(rng.integers(1, 200))
+        it = [Tn // 3, max(2 * Tn // 3, Tn // 3 + 1)] if sampler == "inpainting_ddpm_x0" else None
+        i_f = [20, 120] if (sampler == "inpainting_ddpm_x0" and case % 2) else None
+        p = R.synthetic_params(hp, seed=5000 + case)
+        m = ClassifierFreeDiffRoll(
+            residual_channels=hp["residual_channels"], unconditional=False, condition=hp["condition"], n_mels=hp["n_mels"],
+            norm_args=[0, 1, hp["norm_mode"]], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
+            dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
+            spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000),
+            inpainting_t=it, inpainting_f=i_f, timesteps=hp["timesteps"], training={"mode": "x_0"},
+            sampling={"type": sampler, "w": w}, precision="bf16x3" if case % 5 == 4 else "f32")
+        m.load_state_dict(p)
+        g = torch.Generator().manual_seed(case)
+        wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        noise = torch.randn(hp["timesteps"], B, 1, Tn, 88, generator=g)
+        with torch.no_grad():
+            ref = R.sample_chain(p, hp, sampler, x, wav, noise, w=w, inpainting_t=it, inpainting_f=i_f)
+        roll, _ = m.sample(x, wav, noise=noise)
+        d = maxdiff(roll.cpu(), ref)
+        assert d <= ATOL_STEP, (case, hp, sampler, w, B, Tn, d)
+
+
 def test_forward_with_per_sample_steps_golden(golden_dir):
     """forward() with a (B,) step tensor whose entries differ (dr_forward_steps: the step-embedding row is
     selected per sample in the epilogues) against the reference run; also at full width vs the oracle."""
