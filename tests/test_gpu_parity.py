@@ -702,6 +702,32 @@ def test_random_configurations_vs_oracle():
         assert d <= ATOL_STEP, (case, hp, sampler, w, B, Tn, t, precision, d)
 
 
+def test_random_full_width_geometries_vs_oracle():
+    """Full width (C = 512) with random launch geometries - the tile / split-K / direct-1x1 / dual-epilogue choices
+    are all made from (samples, frames): a shallow net keeps the oracle quick; one guided step per case."""
+    rng = np.random.default_rng(512)
+    for case in range(24):
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_layers=int(rng.integers(2, 5)), kernel_size=int(rng.choice([9, 15])), timesteps=4)
+        Tn = int(rng.choice([1, 33, 64, 65, 96, 125, 127, 128, 129, 160, 200, 256, 333, 640]))
+        B = int(max(1, min(rng.integers(1, 33), 6000 // Tn)))
+        sampler = ["cfdg_ddpm_x0", "generation_ddpm_x0", "ddpm_x0"][case % 3]
+        precision = "bf16x3" if case % 4 == 3 else "f32"
+        p = R.synthetic_params(hp, seed=7000 + case)
+        m = make_model(hp, p, sampler=sampler, w=0.5, precision=precision)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], 4)
+        g = torch.Generator().manual_seed(case)
+        wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        z = torch.randn(B, 1, Tn, 88, generator=g)
+        with torch.no_grad():
+            spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
+            ref = R.reverse_step(p, hp, sch, sampler, x, spec, 2, z, 0.5)
+        out, _ = m.reverse_diffusion(x, wav, 2, noise=z)
+        d = maxdiff(out.cpu(), ref)
+        assert d <= ATOL_STEP, (case, hp["residual_layers"], hp["kernel_size"], sampler, B, Tn, precision, d)
+
+
 def test_random_chains_vs_oracle():
     """Randomised (fixed seed) whole chains through dr_sample (captured graph) against the oracle's loop: random
     depth / width / kernel size / schedule length, the four x0-prediction samplers and the DDIM / epsilon ones,
