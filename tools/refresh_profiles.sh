@@ -21,11 +21,14 @@ python "$R/tools/prof_summary.py" "$OUT/pw" pw "rocprofv3 --pmc WRITE_SIZE TCC_H
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pm" -o pm -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pm.log" 2>&1
 echo "rc=$?"
 python "$R/tools/prof_summary.py" "$OUT/pm" pm "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_mfma.txt"
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pl" -o pl -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pl.log" 2>&1
+echo "rc=$?"
+python "$R/tools/prof_summary.py" "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_lds.txt"
 cd "$R"
 timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "rc=$?"
 timeout 600 python tools/config_bench.py > "$OUT/r01_config_bench.txt" 2>&1
-rm -rf "$OUT/kt" "$OUT/pf" "$OUT/pw" "$OUT/pm"
+rm -rf "$OUT/kt" "$OUT/pf" "$OUT/pw" "$OUT/pm" "$OUT/pl"
 grep -A3 "gemm_kernel<2, 1, 3, 0>" "$OUT/r01_conv_pmc_fetch.txt" "$OUT/r01_conv_pmc_write.txt" "$OUT/r01_conv_pmc_mfma.txt" | grep -v "^--" | head -30
 head -12 "$OUT/r01_kernel_stats.txt"
 cat "$OUT/bench.json" "$OUT/r01_config_bench.txt"
