@@ -1,25 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: piano-roll frames/s for a 200-step reverse-diffusion sample.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1..5}]
+
+``--gpus N`` with N > 1 starts the N ranks itself (re-executes under ``python -m torch.distributed.run``, one
+process per GPU, RCCL); the same script also runs under an external launcher:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): ClassifierFreeDiffRoll k=9, C=512, 15 layers, cfdg_ddpm_x0 w=0.5,
-200 steps, batch 16 per GPU of 4 s / 16 kHz synthetic clips (L=64000 -> T=125 frames), fp32,
-random-init weights.  One "step" of this benchmark = one whole sample of the local batch:
-front-end (STFT/mel/normalise/conditioner projections) + the 200-step hipGraph-captured chain +
-the RCCL gather of the finished rolls + the device->host copy on rank 0.  Inputs are resident in HBM
-when the timed region starts.  Multi-GPU is weak scaling: every rank runs its own 16 clips, the only
-collective is the final all-gather.
+Workloads = BASELINE.json `configs` at their PER-GPU shape; default --config 2, the configuration
+the metric is quoted on: ClassifierFreeDiffRoll k=9, C=512, 15 layers, cfdg_ddpm_x0 w=0.5, 200 steps, batch 16 per
+GPU of 4 s / 16 kHz synthetic clips (L=64000 -> T=125 frames), fp32, random-init weights.  One "step" of this
+benchmark = one whole sample of the local batch: front-end (STFT/mel/normalise/conditioner projections) + the
+hipGraph-captured reverse chain + the RCCL gather of the finished rolls + the device->host copy on rank 0.
+Inputs are resident in HBM when the timed region starts.  Multi-GPU is weak scaling: every rank runs its own
+clips, the only collective is the final all-gather.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (dilated conv + gate implicit
-GEMM on v_mfma_f32_32x32x2_f32): algorithmic FLOPs per launch / mean launch duration measured with
-HIP events on the launch stream in an extra, event-instrumented eager pass of the same chain run
-right after the timed region.  `cpu_baseline` is the CPU oracle (a port of the reference math, torch
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic FLOPs per launch / mean launch
+duration measured with HIP events on the launch stream in an extra, event-instrumented eager pass of the same
+chain run right after the timed region.  `cpu_baseline` is the CPU oracle (a port of the reference math, torch
 CPU fp32) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,14 +37,32 @@ if ROOT not in sys.path:
 HP = dict(residual_channels=512, residual_layers=15, kernel_size=9, dilation_base=2, dilation_bound=4,
           n_mels=229, timesteps=200, beta_start=1e-4, beta_end=0.02, sample_rate=16000, n_fft=2048,
           hop_length=512, f_min=0.0, f_max=8000.0)
-B_LOCAL = 16
-L_SAMPLES = 64000
 W_CFG = 0.5
-SAMPLER = "cfdg_ddpm_x0"
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0
+
+# BASELINE.json configs[0..4] at their per-GPU shape (SURVEY.md 8d "synthetic inputs").  evals = network
+# evaluations per reverse step (2 = conditional + unconditional under classifier-free guidance).
+CONFIGS = {
+    1: dict(k=9, S=50, B=1, L=64000, sampler="cfdg_ddpm_x0", evals=2, gpus_named=1,
+            what="configs[0]: k=9, 50 steps, batch 1, 4 s clip, cfdg_ddpm_x0 w=0.5 (the reference's CPU-runnable case)"),
+    2: dict(k=9, S=200, B=16, L=64000, sampler="cfdg_ddpm_x0", evals=2, gpus_named=1,
+            what="configs[1]: k=9 transcription, cfdg_ddpm_x0 w=0.5, 200 steps, batch 16 per GPU, 4 s @16 kHz clips"),
+    3: dict(k=9, S=200, B=16, L=64000, sampler="generation_ddpm_x0", evals=1, gpus_named=8,
+            what="configs[2]: k=9 unconditional generation (spec = -1), 200 steps, batch 128 over 8 GPUs = 16 per GPU"),
+    4: dict(k=9, S=200, B=16, L=64000, sampler="inpainting_ddpm_x0", evals=2, gpus_named=4,
+            what="configs[3]: k=9 inpainting (spectrogram frames [T/4, T/2) masked), w=0.5, 200 steps, batch 64 over "
+                 "4 GPUs = 16 per GPU, hipGraph-captured chain"),
+    5: dict(k=15, S=200, B=4, L=327680, sampler="cfdg_ddpm_x0", evals=2, gpus_named=8,
+            what="configs[4]: k=15, 640-frame segments, cfdg_ddpm_x0 w=0.5, 200 steps, batch 32 over 8 GPUs = 4 per GPU"),
+}
+# module-level aliases of the default workload (tools/ import them)
+B_LOCAL = CONFIGS[2]["B"]
+L_SAMPLES = CONFIGS[2]["L"]
+SAMPLER = CONFIGS[2]["sampler"]
 
 
-def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0):
+def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0, inpainting_t=None):
     from diffroll_amd import ClassifierFreeDiffRoll
     torch.manual_seed(seed)
     m = ClassifierFreeDiffRoll(
@@ -51,8 +72,8 @@ def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0):
         spec_args=dict(sample_rate=hp["sample_rate"], n_fft=hp["n_fft"], hop_length=hp["hop_length"],
                        n_mels=hp["n_mels"], f_min=hp["f_min"], f_max=hp["f_max"], center=True,
                        normalized=True, pad_mode="reflect"),
-        spec_dropout=0.1, timesteps=hp["timesteps"], beta_start=hp["beta_start"], beta_end=hp["beta_end"],
-        training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, device=device)
+        spec_dropout=0.1, inpainting_t=inpainting_t, timesteps=hp["timesteps"], beta_start=hp["beta_start"],
+        beta_end=hp["beta_end"], training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, device=device)
     # the reference zero-initialises the output projection (model/diffwave.py:630): re-draw it so the
     # synthetic network is input dependent
     torch.nn.init.normal_(m.output_projection.weight, 0.0, 0.02)
@@ -60,28 +81,67 @@ def build_model(device, hp=HP, sampler=SAMPLER, w=W_CFG, seed=0):
     return m
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes); counters
-    cannot be collected live from inside the timed process, so this is the per-round profile value."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_conv_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+def csrc_digest():
+    """sha256 over the kernel sources: counter profiles under profiles/ are stamped with it, so a stale
+    profile is detected instead of silently reported."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "diffroll_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(model, budget_s=12.0, max_steps=40):
+def pmc_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes; tools/refresh_profiles.sh).
+    Counters cannot be collected from inside the timed process, so the value comes from the newest committed
+    profile - and is reported only when that profile was taken from THESE kernel sources (csrc digest) for THIS
+    kernel; otherwise null with the reason."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except Exception:       # noqa: BLE001
+            continue
+        if j.get("kernel_tag") != kernel_tag:
+            continue
+        if j.get("csrc_digest") != csrc_digest():
+            return None, f"{os.path.basename(path)} was taken from other kernel sources (digest {j.get('csrc_digest')})"
+        return j["hbm_bytes_per_launch"], os.path.basename(path)
+    return None, "no committed PMC profile for this kernel"
+
+
+def flops_per_frame_eval(k, C=512, Lr=15):
+    """algorithmic FLOPs per frame per network evaluation (conditioner / embedding hoisted)."""
+    return 2 * 88 * C + Lr * (2 * C * 2 * C * k + 2 * C * 2 * C) + 2 * C * C + 2 * C * 88
+
+
+def chain_bytes(cfg, T):
+    """layer-granular compulsory HBM bytes of one chain on one GPU."""
+    C, Lr, k, M = HP["residual_channels"], HP["residual_layers"], cfg["k"], 88
+    w_bytes = 4 * (M * C + C + Lr * (2 * C * C * k + 2 * C + 2 * C * C + 2 * C) + C * C + C + C * M + M)
+    a_uncond = M * 4 + Lr * (C * 4 + C * 4 + 2 * C * 4) + C * 4 + M * 4      # read h, write h, skip RMW per layer
+    a_cond = a_uncond + Lr * 2 * C * 4
+    per_frame = {"cfdg_ddpm_x0": a_cond + a_uncond, "inpainting_ddpm_x0": a_cond + a_uncond,
+                 "generation_ddpm_x0": a_uncond}[cfg["sampler"]]
+    return cfg["S"] * (cfg["evals"] * w_bytes + cfg["B"] * T * (per_frame + 3 * M * 4))
+
+
+def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
     """The oracle (CPU port of the reference arithmetic) on this box's host cores, bounded sample."""
     from oracle import diffroll_ref as R           # checker / baseline only - never the product path
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    hp = dict(HP)
-    T = L_SAMPLES // hp["hop_length"]
+    B, Ls, sampler = cfg["B"], cfg["L"], cfg["sampler"]
+    T = Ls // hp["hop_length"]
+    S = hp["timesteps"]
     g = torch.Generator().manual_seed(1)
-    wav = 0.1 * torch.randn(B_LOCAL, L_SAMPLES, generator=g)
-    x = torch.randn(B_LOCAL, 1, T, 88, generator=g)
-    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
-    table = R.build_embedding(hp["timesteps"])
+    wav = 0.1 * torch.randn(B, Ls, generator=g)
+    x = torch.randn(B, 1, T, 88, generator=g)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], S)
+    table = R.build_embedding(S)
     default_threads = torch.get_num_threads()
     with torch.no_grad():
         spec = R.frontend(wav, hp, T)
@@ -93,7 +153,7 @@ def cpu_baseline(model, budget_s=12.0, max_steps=40):
         for cand in sorted({c for c in (4, 8, 16, 32, 64, 128, default_threads) if c <= (os.cpu_count() or 1)}):
             torch.set_num_threads(cand)
             t0 = time.perf_counter()
-            R.reverse_step(params, hp, sch, SAMPLER, x, spec, hp["timesteps"] - 1, z0, W_CFG, table)
+            R.reverse_step(params, hp, sch, sampler, x, spec, S - 1, z0, W_CFG, table)
             dt_c = time.perf_counter() - t0
             if dt_c < best_t:
                 best_n, best_t = cand, dt_c
@@ -106,10 +166,10 @@ def cpu_baseline(model, budget_s=12.0, max_steps=40):
         t_front = time.perf_counter() - t0
         n = 0
         t0 = time.perf_counter()
-        while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget_s):
-            t_index = hp["timesteps"] - 1 - n
+        while n < min(max_steps, S) and (n == 0 or time.perf_counter() - t0 < budget_s):
+            t_index = S - 1 - n
             z = torch.randn(x.shape, generator=g)
-            x = R.reverse_step(params, hp, sch, SAMPLER, x, spec, t_index, z, W_CFG, table)
+            x = R.reverse_step(params, hp, sch, sampler, x, spec, t_index, z, W_CFG, table)
             n += 1
         t_steps = time.perf_counter() - t0
         # BASELINE.md section 3 also asks for the single-thread figure: one reverse step of ONE clip, scaled to the
@@ -117,12 +177,12 @@ def cpu_baseline(model, budget_s=12.0, max_steps=40):
         torch.set_num_threads(1)
         try:
             t0 = time.perf_counter()
-            R.reverse_step(params, hp, sch, SAMPLER, x[:1], spec[:1], hp["timesteps"] - 1, z[:1], W_CFG, table)
+            R.reverse_step(params, hp, sch, sampler, x[:1], spec[:1], S - 1, z[:1], W_CFG, table)
             t_one = time.perf_counter() - t0
         finally:
             torch.set_num_threads(default_threads)
     per_step = t_steps / n
-    total = t_front + per_step * hp["timesteps"]
+    total = t_front + per_step * S
     model_name = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -133,13 +193,13 @@ def cpu_baseline(model, budget_s=12.0, max_steps=40):
     except OSError:
         pass
     return {
-        "value": round(B_LOCAL * T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{n} of 200 reverse steps (2 network evaluations each) at B={B_LOCAL},T={T} + one front-end, "
-                  f"{t_steps + t_front:.1f} s of CPU work, extrapolated to the 200-step chain",
+        "value": round(B * T / total, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+        "sample": f"{n} of {S} reverse steps ({cfg['evals']} network evaluation(s) each) at B={B},T={T} + one "
+                  f"front-end, {t_steps + t_front:.1f} s of CPU work, extrapolated to the {S}-step chain",
         "os_cpu_count": os.cpu_count(), "cpu_model": model_name, "s_per_step": round(per_step, 4),
         "threads_note": f"thread count chosen by a short ascending sweep over 4..128 (os.cpu_count() = {os.cpu_count()})",
-        "single_thread": {"value": round(T / (t_one * hp["timesteps"]), 3), "unit": "frames/s", "cores": 1,
-                          "sample": f"1 reverse step of 1 clip ({t_one:.1f} s), extrapolated to 200 steps"},
+        "single_thread": {"value": round(T / (t_one * S), 3), "unit": "frames/s", "cores": 1,
+                          "sample": f"1 reverse step of 1 clip ({t_one:.1f} s), extrapolated to {S} steps"},
     }
 
 
@@ -148,46 +208,53 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json config (1-based) at its per-GPU shape; default 2 = the headline workload")
+    ap.add_argument("--dist", action="store_true",
+                    help="plain single-process run: still create a 1-rank RCCL group (exercises init / all-gather / barrier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N ...")
+    from diffroll_amd import launch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if not launch.under_launcher() and args.gpus > 1:
+        # `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU over RCCL)
+        sys.exit(launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    rank, world, local_rank = launch.rank_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # host-side torch ops here are tiny; keep N ranks from each spawning one CPU thread per hardware thread
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    dist = None
-    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also at N = 1)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dist = launch.init_process_group(device, force_single=args.dist)
 
     from diffroll_amd.distributed import gather_rolls
 
-    model = build_model(device)
-    T = L_SAMPLES // HP["hop_length"]
-    S = HP["timesteps"]
-    # synthetic inputs, resident in HBM; global sample index = rank * B_LOCAL + b
+    cfg = CONFIGS[args.config]
+    hp = dict(HP)
+    hp.update(kernel_size=cfg["k"], timesteps=cfg["S"])
+    B, Ls, S, sampler = cfg["B"], cfg["L"], cfg["S"], cfg["sampler"]
+    T = Ls // hp["hop_length"]
+    inp_t = [T // 4, T // 2] if sampler == "inpainting_ddpm_x0" else None
+    model = build_model(device, hp=hp, sampler=sampler, inpainting_t=inp_t)
+    # synthetic inputs, resident in HBM; global sample index = rank * B + b
     g = torch.Generator().manual_seed(1000 + rank)
-    wav = (0.1 * torch.randn(B_LOCAL, L_SAMPLES, generator=g)).to(device)
-    x_T = torch.randn(B_LOCAL, 1, T, 88, generator=g).to(device)
+    wav = (0.1 * torch.randn(B, Ls, generator=g)).to(device)
+    x_T = torch.randn(B, 1, T, 88, generator=g).to(device)
     model.engine   # create + commit (weight packing / upload) outside the timed region
 
     def one_step():
         model._fe_key = None                                   # front-end is part of every sample
-        roll, _ = model.sample(x_T, wav, seed=0, first_sample=rank * B_LOCAL)   # on-device Philox noise
-        full = gather_rolls(roll)                              # RCCL all-gather (no-op at N=1)
+        roll, _ = model.sample(x_T, wav, seed=0, first_sample=rank * B)   # on-device Philox noise
+        full = gather_rolls(roll)                              # RCCL all-gather (no-op without a process group)
         if rank == 0:
             return full.cpu()
         return None
@@ -197,66 +264,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n):
+        sync()
+        t0 = time.perf_counter()
+        o = None
+        for _ in range(n):
+            o = one_step()
+        sync()
+        dt_ = time.perf_counter() - t0
+        tt = torch.tensor([dt_], device=device, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), o
+
     for _ in range(args.warmup):
         one_step()
-    sync()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = one_step()
-    sync()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt, out = timed(args.steps)
 
-    frames = world * B_LOCAL * T * args.steps
+    frames = world * B * T * args.steps
     result = {
-        "metric": "piano-roll frames/sec (200-step sample)", "value": round(frames / dt, 2), "unit": "frames/s",
+        "metric": "piano-roll frames/sec (200-step sample)" if S == 200 else f"piano-roll frames/sec ({S}-step sample)",
+        "value": round(frames / dt, 2), "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: ClassifierFreeDiffRoll k=9 C=512 L=15, cfdg_ddpm_x0 w=0.5, "
-                               "200 steps, batch 16 per GPU, 4 s @16 kHz clips (T=125), random-init weights, "
-                               "Philox noise, front-end + chain + gather + D2H per step",
-                   "batch_per_gpu": B_LOCAL, "frames_per_clip": T, "diffusion_steps": S,
-                   "kernel_size": HP["kernel_size"], "sampler": SAMPLER, "w": W_CFG,
-                   "parallelism": f"batch-shard x{world}", "graph": True},
+        "config": {"workload": f"BASELINE {cfg['what']} (T={T}); ClassifierFreeDiffRoll C=512 L=15, random-init "
+                               "weights, Philox noise, front-end + chain + gather + D2H per step",
+                   "baseline_config": args.config, "batch_per_gpu": B, "frames_per_clip": T, "diffusion_steps": S,
+                   "kernel_size": cfg["k"], "sampler": sampler, "w": W_CFG if cfg["evals"] == 2 else None,
+                   "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True},
+        "dist": launch.dist_info(dist),
     }
     if rank == 0:
-        assert out is not None and bool(torch.isfinite(out).all()) and out.shape == (world * B_LOCAL, 1, T, 88)
+        assert out is not None and bool(torch.isfinite(out).all()) and out.shape == (world * B, 1, T, 88)
         # the metric also asks for the HBM-roofline fraction: SURVEY.md 8(d) algorithmic bytes of one chain per GPU
         # (weights streamed once per evaluation + layer-granular activation traffic + the update) over the chain time
-        C, Lr, k, M = HP["residual_channels"], HP["residual_layers"], HP["kernel_size"], 88
-        w_bytes = 4 * (M * C + C + Lr * (2 * C * C * k + 2 * C + 2 * C * C + 2 * C) + C * C + C + C * M + M)
-        a_uncond = M * 4 + Lr * (C * 4 + C * 4 + 2 * C * 4) + C * 4 + M * 4      # read h, write h, skip RMW per layer
-        a_cond = a_uncond + Lr * 2 * C * 4
-        chain_bytes = S * (2 * w_bytes + B_LOCAL * T * (a_cond + a_uncond + 3 * M * 4))
-        gbps = chain_bytes / (dt / args.steps) / 1e9
-        result["hbm_roofline"] = {"algorithmic_bytes_per_chain_per_gpu": chain_bytes, "achieved_gbps_per_gpu": round(gbps, 1),
-                                  "peak_gbps": 8000.0, "frac": round(gbps / 8000.0, 4),
+        cb = chain_bytes(cfg, T)
+        gbps = cb / (dt / args.steps) / 1e9
+        fl = flops_per_frame_eval(cfg["k"]) * B * T * cfg["evals"] * S
+        result["hbm_roofline"] = {"algorithmic_bytes_per_chain_per_gpu": cb, "achieved_gbps_per_gpu": round(gbps, 1),
+                                  "peak_gbps": PEAK_HBM_GBPS, "frac": round(gbps / PEAK_HBM_GBPS, 4),
                                   "note": "the step is MFMA-bound in fp32 (see roofline); reported because the metric names it"}
+        result["whole_chain"] = {"algorithmic_tflop_per_chain_per_gpu": round(fl / 1e12, 2),
+                                 "achieved_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 2),
+                                 "frac_of_fp32_mfma_peak": round(fl / (dt / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
 
     if rank == 0 and not args.no_roofline:
         eng = model.engine
         eng.profile_enable(True)
         model._fe_key = None
         model.sample(x_T, wav, seed=0, first_sample=0, use_graph=False)
-        launches, ms = eng.profile_read(reset=True)
+        launches, ms, flops, kname = eng.profile_read_ex(reset=True)
         eng.profile_enable(False)
-        k = HP["kernel_size"]
-        C = HP["residual_channels"]
-        flops_per_frame = 2.0 * C * (2 * C) * k            # 2*512*1024*k per frame per layer
-        frames_per_launch = 2 * B_LOCAL * T                # conditional + unconditional batch
+        # the timed kernel is the engine's dominant one for this launch geometry: the fused residual-stack kernel
+        # (all residual layers of one evaluation in one persistent launch) or, where that does not apply, the
+        # dilated conv + gate kernel.  flops = SURVEY.md 8(d) per-frame figures x the frames each launch processed.
         avg_s = ms * 1e-3 / max(launches, 1)
-        achieved = flops_per_frame * frames_per_launch / avg_s / 1e12
+        achieved = flops / max(ms * 1e-3, 1e-12) / 1e12
+        tag = "stack" if kname.startswith("stack_kernel") else "conv_gate"
+        traffic, traffic_src = pmc_traffic(f"{tag}:config{args.config}")
         result["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_kernel<2,EPI_GATE> (dilated conv k=9 + conditioner + gate)",
+            "bound": "mfma", "kernel": kname,
             "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": pmc_traffic(),
+            "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "launches": launches, "avg_launch_us": round(avg_s * 1e6, 2),
-            "flops_per_launch": flops_per_frame * frames_per_launch,
+            "flops_per_launch": flops / max(launches, 1),
             "share_of_step_time": round((ms * 1e-3) / (dt / args.steps), 4),
         }
     if not args.no_split:
@@ -265,17 +337,7 @@ def main():
         # Reported NEXT TO the headline, never as `value`: same workload, same seeds, same timing protocol.
         model.precision = "bf16x3"
         one_step()
-        sync()
-        t0 = time.perf_counter()
-        out3 = None
-        for _ in range(args.steps):
-            out3 = one_step()
-        sync()
-        dt3 = time.perf_counter() - t0
-        tt3 = torch.tensor([dt3], device=device, dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(tt3, op=dist.ReduceOp.MAX)
-        dt3 = float(tt3.item())
+        dt3, out3 = timed(args.steps)
         model.precision = "f32"
         model.engine
         if rank == 0:
@@ -286,7 +348,7 @@ def main():
                 "note": "opt-in precision mode; identical inputs and Philox noise as the headline run",
             }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(model)
+        result["cpu_baseline"] = cpu_baseline(model, cfg, hp)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

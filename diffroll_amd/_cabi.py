@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 5
+DR_ABI_VERSION = 6
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
 
 SAMPLERS = {
@@ -35,6 +35,7 @@ EXPORTS = [
     "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
     "dr_extract_x0", "dr_set_spec_norm", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
+    "dr_profile_read_ex", "dr_set_option", "dr_stack_status",
 ]
 
 
@@ -102,6 +103,13 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_profile_enable.argtypes = [vp, C.c_int]
     lib.dr_profile_read.restype = C.c_int
     lib.dr_profile_read.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]
+    lib.dr_profile_read_ex.restype = C.c_int
+    lib.dr_profile_read_ex.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.c_char_p, C.c_size_t, C.c_int]
+    lib.dr_set_option.restype = C.c_int
+    lib.dr_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    lib.dr_stack_status.restype = C.c_int
+    lib.dr_stack_status.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int]
     lib.dr_bench_layer.restype = C.c_int
     lib.dr_bench_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.dr_bench_pointwise.restype = C.c_int

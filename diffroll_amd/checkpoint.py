@@ -8,13 +8,17 @@ importable.  Neither is a dependency here: unknown classes are unpickled into in
 record their state, and OmegaConf containers are then converted to plain dict / list / scalars.
 
 The converter knows the pickled shape of OmegaConf 2.x nodes (containers keep their children in
-``_content``, value nodes their payload in ``_val``); it cannot be checked against a real reference
-checkpoint in this environment (none is available) and is exercised with synthetic stand-ins in the tests.
+``_content``, value nodes their payload in ``_val``); and resolves
+their string interpolations (``sample_rate: ${sampling_rate}``, ``hop_length: ${hop_length}`` in config/spec/mel.yaml
+reach the checkpoint unresolved, train_spec_roll.py:30) against the root of the node's ``_parent`` chain.  It cannot
+be checked against a real reference checkpoint in this environment (none is available) and is exercised with
+synthetic stand-ins in the tests.
 """
 from __future__ import annotations
 
 import inspect
 import pickle
+import re
 from typing import Any, Dict
 
 import torch
@@ -60,31 +64,106 @@ class _TolerantPickle:
         return TolerantUnpickler(f, **kwargs).load()
 
 
-def to_plain(obj: Any) -> Any:
-    """Stand-ins / OmegaConf-shaped nodes -> plain Python (dict, list, scalars)."""
+def _state(obj) -> Any:
+    """The recorded state of a stand-in as one dict (pickle's (dict, slots) form is merged)."""
+    state = obj._dr_state
+    if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):
+        merged = dict(state[0] or {})
+        merged.update(state[1])
+        state = merged
+    return state
+
+
+def _root_of(obj) -> Any:
+    """OmegaConf nodes keep their container in `_parent`; the root of that chain is where `${a.b}` looks keys up."""
+    seen = set()
+    while isinstance(obj, _Stub) and id(obj) not in seen:
+        seen.add(id(obj))
+        st = _state(obj)
+        parent = st.get("_parent") if isinstance(st, dict) else None
+        if not isinstance(parent, _Stub):
+            return obj
+        obj = parent
+    return obj
+
+
+_INTERP = re.compile(r"\$\{([^${}]+)\}")
+
+
+def _select(container, dotted: str):
+    """Raw (unresolved) node at `a.b.c` below an OmegaConf-shaped container stand-in; KeyError if absent."""
+    node = container
+    for part in [p for p in dotted.split(".") if p != ""]:
+        st = _state(node) if isinstance(node, _Stub) else node
+        content = st.get("_content") if isinstance(st, dict) and "_content" in st else st
+        if isinstance(content, dict):
+            if part not in content:
+                raise KeyError(dotted)
+            node = content[part]
+        elif isinstance(content, (list, tuple)):
+            node = content[int(part)]
+        else:
+            raise KeyError(dotted)
+    return node
+
+
+def _resolve(text: str, node, depth: int = 0) -> Any:
+    """OmegaConf interpolation of a value node's string: `${a.b}` is looked up from the ROOT of the node's `_parent`
+    chain, `${.a}` / `${..a}` relative to the node's container (one level up per extra dot).  Resolver calls
+    (`${now:...}`, `${hydra:...}`) and keys that cannot be found are left as they are - the consumer of that
+    value then fails with the unresolved text in its message instead of a silent wrong value."""
+    if depth > 16 or "${" not in text:
+        return text
+
+    def lookup(key: str):
+        if ":" in key:
+            raise KeyError(key)
+        if key.startswith("."):
+            ups = len(key) - len(key.lstrip("."))
+            base = node
+            for _ in range(ups):
+                st = _state(base) if isinstance(base, _Stub) else None
+                base = st.get("_parent") if isinstance(st, dict) else None
+                if base is None:
+                    raise KeyError(key)
+            target = _select(base, key.lstrip("."))
+        else:
+            target = _select(_root_of(node), key)
+        return to_plain(target, depth + 1)
+
+    m = _INTERP.fullmatch(text.strip())
+    try:
+        if m:                                   # the whole value is one interpolation: keep the target's type
+            return lookup(m.group(1).strip())
+        return _INTERP.sub(lambda mm: str(lookup(mm.group(1).strip())), text)
+    except (KeyError, IndexError, ValueError):
+        return text
+
+
+def to_plain(obj: Any, _depth: int = 0) -> Any:
+    """Stand-ins / OmegaConf-shaped nodes -> plain Python (dict, list, scalars), interpolations resolved."""
     if isinstance(obj, _Stub):
-        state = obj._dr_state
-        if isinstance(state, tuple) and len(state) == 2 and isinstance(state[1], dict):   # (dict, slots) form
-            merged = dict(state[0] or {})
-            merged.update(state[1])
-            state = merged
+        state = _state(obj)
         if isinstance(state, dict):
             if "_content" in state:
-                return to_plain(state["_content"])
+                return to_plain(state["_content"], _depth)
             if "_val" in state:
-                return to_plain(state["_val"])
+                val = state["_val"]
+                if isinstance(val, str) and "${" in val:
+                    return _resolve(val, obj, _depth)
+                return to_plain(val, _depth)
             if "_value_" in state:                      # enum members
-                return to_plain(state["_value_"])
+                return to_plain(state["_value_"], _depth)
         if obj._dr_args:                                # e.g. enums reduced to (value,)
-            return to_plain(obj._dr_args[0]) if len(obj._dr_args) == 1 else [to_plain(a) for a in obj._dr_args]
+            return to_plain(obj._dr_args[0], _depth) if len(obj._dr_args) == 1 else [to_plain(a, _depth) for a in obj._dr_args]
         return None
     if isinstance(obj, dict):
-        return {to_plain(k) if isinstance(k, _Stub) else k: to_plain(v) for k, v in obj.items()}
+        return {to_plain(k, _depth) if isinstance(k, _Stub) else k: to_plain(v, _depth) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
-        return [to_plain(v) for v in obj]
+        return [to_plain(v, _depth) for v in obj]
     if hasattr(obj, "items") and not isinstance(obj, (str, bytes)) and not torch.is_tensor(obj):
         try:                                            # a real OmegaConf container when omegaconf IS installed
-            return {k: to_plain(v) for k, v in obj.items()}
+            return {k: to_plain(v, _depth) for k, v in obj.items()}
         except Exception:
             pass
     return obj

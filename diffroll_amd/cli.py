@@ -130,13 +130,15 @@ def make_model(cfg: Dict[str, Any], device):
                   generation_filter=task["generation_filter"], sampling=task["sampling"],
                   inpainting_t=task["inpainting_t"], inpainting_f=task["inpainting_f"], training={"mode": "x_0"})
     path = cfg["checkpoint_path"]
-    if path and os.path.exists(path):
+    if path:
+        # a named checkpoint must exist (the reference fails in load_from_checkpoint, sampling.py:54): random
+        # weights are only ever used when NO checkpoint is named
+        if not os.path.exists(path):
+            raise SystemExit(f"checkpoint_path '{path}' does not exist")
         # keyword overrides win over the checkpoint's hyper_parameters (sampling.py:54-65)
         m = ClassifierFreeDiffRoll.load_from_checkpoint(path, **{k: kwargs[k] for k in (
             "sampling", "frame_threshold", "generation_filter", "inpainting_t", "inpainting_f")})
     else:
-        if path:
-            warnings.warn(f"checkpoint '{path}' not found: using randomly initialised weights")
         m = ClassifierFreeDiffRoll(**cfg["model"]["args"], **kwargs)
         torch.nn.init.normal_(m.output_projection.weight, 0.0, 0.02)
     m.precision = cfg.get("precision", "f32")
@@ -147,15 +149,17 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
     cfg = build_config(list(sys.argv[1:] if argv is None else argv), default_task)
     if not torch.cuda.is_available():
         raise SystemExit("sampling needs an MI355X: diffroll_amd has no CPU fallback")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from . import launch
+    gpus = int(cfg.get("gpus") or 1)
+    if gpus > 1 and not launch.under_launcher():
+        # `gpus=N` is the reference's one flag for N devices (Trainer(gpus=cfg.gpus), sampling.py:70): start the
+        # N ranks here, one process per GPU
+        script = os.path.abspath(sys.argv[0]) if argv is None else os.path.abspath(sys.modules["__main__"].__file__)
+        raise SystemExit(launch.spawn_ranks(gpus, script, list(sys.argv[1:] if argv is None else argv)))
+    rank, world, local_rank = launch.rank_env()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dist = launch.init_process_group(device) if world > 1 else None
     from .distributed import sample_sharded
 
     S = int(cfg["dataset"]["num_samples"])
@@ -193,8 +197,7 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
         print(f"{cfg['task']['name']}: {S} clips x {T} frames, {cfg['task']['timesteps']} steps, sampler "
               f"{cfg['task']['sampling']['type']}, {world} GPU(s): {dt:.2f} s ({S * T / dt:.1f} frames/s incl. load "
               f"and capture) -> {cfg['output_dir']}/")
-    if world > 1:
-        import torch.distributed as dist
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

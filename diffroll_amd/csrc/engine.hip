@@ -103,7 +103,21 @@ struct dr_engine {
     size_t tsel_cap = 0;
     bool use_dyn = false;               // set while the chain is being captured: run_step points the update at d_dyn
 
+    // fused residual stack (stack_kernel): one persistent launch for the residual layers when every block of the
+    // launch is resident at once; opt_stack 0 = always one launch per phase
+    int opt_stack = 1;
+    int opt_stack_xcd = 1;              // group-per-XCD block mapping (0: weight-panel-per-XCD)
+    int n_cus = 0;
+    unsigned* stack_bar = nullptr;      // [STACK_GROUPS][2] group counters, zero between launches
+    unsigned* stack_err = nullptr;
+    unsigned* stack_xid = nullptr;      // [n_cus-sized] XCC ids published by the blocks of the last launch
+    long long* stack_dbg = nullptr;     // phase tick marks of block 0 (dr_debug_stack_ticks)
+    int stack_dbg_on = 0;
+    static constexpr int STACK_GROUPS = 512;
+
     // profiling of the dominant kernel
+    double prof_flops = 0.0;            // algorithmic FLOPs of the timed launches
+    std::string prof_name;
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
@@ -132,6 +146,20 @@ int fail(dr_engine* e, int code, const char* fmt, ...) {
     } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Every entry point runs on the engine's device and leaves the caller's current device as it found it (a process
+// that drives several GPUs must not have its device switched by constructing or calling an engine).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // roctx ranges around the host-side phases (rocprofv3 --marker-trace shows them next to the kernel trace).  The
 // marker library is looked up at run time: no link-time dependency, silent no-ops when it is absent.
@@ -461,7 +489,65 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         allow_splitk(e, a);
         HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
     }
-    for (int l = 0; l < L; ++l) {
+    // ---- fused residual stack: the layers as ONE persistent launch when all its blocks are resident at once ----
+    // (exact fp32 only; the first layer's conv stays a launch of its own under classifier-free guidance, where it
+    // is contracted once per (conditional, unconditional) pair)
+    int stack_from = -1;                   // first phase run by the fused kernel (-1: none)
+    int stack_ni = 0;
+    if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
+        int maxdil = 1;
+        for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
+        for (int ni = 1; ni <= 2 && !stack_ni; ++ni) {        // smallest frame tile whose launch is one resident round
+            const long blocks = (long)(Cp / 64) * NB * ((T + 64 * ni - 1) / (64 * ni));
+            if (blocks <= e->n_cus && blocks <= 1024 && 2 * blocks >= e->n_cus && NB <= dr_engine::STACK_GROUPS &&
+                gemm_lds_bytes(ni, 1, e->K, maxdil, 0, EPI_GATE) + (size_t)32 * 64 * ni * 16 <= 160 * 1024)
+                stack_ni = ni;
+        }
+        const bool dual0 = (bmod > 0 && NB == 2 * bmod && n_cond == bmod);
+        if (stack_ni) stack_from = dual0 ? 1 : 0;
+    }
+    auto launch_stack_range = [&](int p0, int p1) -> int {
+        StackArgs sa{};
+        sa.h = e->h; sa.hd = e->hd; sa.g = e->g; sa.skip = e->skip;
+        sa.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
+        sa.tsel = tsel; sa.d2_ts = (long)L * Cp;
+        sa.zero = zero_vec();
+        sa.NB = NB; sa.T = T; sa.Cp = Cp; sa.taps = e->K; sa.n_cond = n_cond; sa.L = L;
+        sa.c_bs = (long)2 * Cp * T;
+        sa.p0 = p0; sa.p1 = p1;
+        sa.xcd_n = e->opt_stack_xcd;
+        sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
+        sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
+        int maxdil = 1;
+        for (int l = 0; l < L; ++l) {
+            const LayerW& w = e->layers[l];
+            StackLayer& y = sa.layer[l];
+            y.conv_w = w.conv_w; y.conv_b = w.conv_b;
+            y.conv_b2 = zero_spec ? w.conv_b_z : w.conv_b_u;
+            y.cond2 = nullptr;
+            if (e->cond_tr && !zero_spec) { y.cond2 = e->cond_tr + (size_t)l * 2 * Cp * T; y.conv_b2 = w.conv_b; }
+            y.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
+            y.out_w = w.out_w; y.out_b = w.out_b; y.dil = w.dil;
+            maxdil = std::max(maxdil, w.dil);
+        }
+        const bool timed = e->prof && e->prof_used < e->prof_events.size();
+        if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
+        HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
+        if (timed) {
+            HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
+            const double C = e->C, fr = (double)NB * T;
+            for (int p = p0; p < p1; ++p) e->prof_flops += fr * 2.0 * C * 2.0 * C * ((p & 1) ? 1.0 : (double)e->K);
+            e->prof_name = "stack_kernel<" + std::to_string(stack_ni) + "> (fused residual stack: dilated conv k=" +
+                           std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
+                           std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) + ")";
+        }
+        return DR_OK;
+    };
+    if (stack_from == 0) {
+        int rc = launch_stack_range(0, 2 * L);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < L && stack_from != 0; ++l) {
         const LayerW& w = e->layers[l];
         {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
             GemmArgs a = p4_gemm(prec ? w.conv_w3 : w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
@@ -485,10 +571,20 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if (dual) { a.NB = bmod; a.dual = bmod; }
             const Tile tile = dual ? pick_tile(Cp / 64, bmod, T, e->K, w.dil, prec, EPI_GATE, false)
                                    : pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true);
-            const bool timed = e->prof && !dual && e->prof_used < e->prof_events.size();
+            if (e->stack_dbg_on && l + 1 == L) a.dbg = e->stack_dbg + 64;
+            const bool timed = e->prof && !dual && stack_from < 0 && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
             HIPCHK(e, launch_tiled(a, EPI_GATE, tile, st, prec));
-            if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
+            if (timed) {
+                HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
+                e->prof_flops += (double)NB * T * 2.0 * e->C * 2.0 * e->C * e->K;
+                e->prof_name = "gemm_kernel<EPI_GATE> (dilated conv k=" + std::to_string(e->K) + " + conditioner + gate)";
+            }
+        }
+        if (stack_from == 1) {             // layer 0's conv ran above; everything from its 1x1 on is one launch
+            int rc = launch_stack_range(1, 2 * L);
+            if (rc) return rc;
+            break;
         }
         {   // 1x1 output projection, residual and skip (model/diffwave.py:149-151, :680)
             GemmArgs a = p4_gemm(prec ? w.out_w3 : w.out_w, w.out_b, Cp / 64, e->g, P, NB, T);
@@ -502,6 +598,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             }
             a.skip = e->skip; a.s_bs = (long)Cp * T; a.skip_init = (l == 0);
             allow_splitk(e, a);
+            if (e->stack_dbg_on && l + 2 == L) a.dbg = e->stack_dbg + 96;     // same tick marks as the fused kernel's
             Tile tile = pick_pointwise_tile(Cp / 64, NB, T, prec);
             // the last layer's residual output is never read (model/diffwave.py:678-682 only uses the skip sum
             // after the loop): launch the skip half of the M tiles only
@@ -575,7 +672,6 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
 int check_ready(dr_engine* e, int sampler, int B, int T) {
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
-    HIPCHK(e, hipSetDevice(e->cfg.device));      // every entry point runs on the engine's device, whatever is current
     if (sampler != DR_SAMPLER_GENERATION_DDPM_X0 && (e->fe_B != B || e->fe_T != T))
         return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
                     e->fe_B, e->fe_T, B, T);
@@ -607,7 +703,11 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, DR_EHIP, "no HIP device available: the engine has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DR_EINVAL, "device %d out of range", cfg->device);
-    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DR_EHIP, "hipSetDevice failed");
+    DeviceGuard guard(cfg->device);
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) return fail(nullptr, DR_EHIP, "hipSetDevice failed");
+    }
     {
         hipError_t ie = init_kernels();
         if (ie != hipSuccess) return fail(nullptr, DR_EHIP, "kernel init failed: %s", hipGetErrorString(ie));
@@ -630,6 +730,8 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
     e->K = cfg->kernel_size;
     e->S = cfg->timesteps;
     e->NM = cfg->n_mels;
+    if (const char* v = getenv("DR_STACK")) e->opt_stack = atoi(v);           // tuning / A-B experiments
+    if (const char* v = getenv("DR_STACK_XCD")) e->opt_stack_xcd = atoi(v);
     e->n_bins = cfg->n_fft / 2 + 1;
     e->bins_p = round_up(e->n_bins, 64);
     int maxdil = 1;
@@ -649,7 +751,7 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
 
 void dr_destroy(dr_engine* e) {
     if (!e) return;
-    (void)hipSetDevice(e->cfg.device);
+    DeviceGuard guard(e->cfg.device);
     (void)hipDeviceSynchronize();
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
@@ -657,6 +759,8 @@ void dr_destroy(dr_engine* e) {
     if (e->dbg_ticks) (void)hipFree(e->dbg_ticks);
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
+    if (e->stack_bar) (void)hipFree(e->stack_bar);
+    if (e->stack_dbg) (void)hipFree(e->stack_dbg);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
     if (e->d_tsel) (void)hipFree(e->d_tsel);
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -689,7 +793,7 @@ int dr_commit(dr_engine* e, void* stream) {
     if (!e) return DR_EINVAL;
     Range range("dr_commit: pack + upload weights, hoisted tables");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     if (e->h_emb.empty() || e->h_coef.empty()) return fail(e, DR_ESTATE, "dr_set_tables has not been called");
     const int C = e->C, Cp = e->Cp, L = e->L, K = e->K, NM = e->NM, S = e->S;
     // all parameters present?
@@ -854,6 +958,22 @@ int dr_commit(dr_engine* e, void* stream) {
         e->sk_cnt = (unsigned*)q;
     }
     if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
+    if (!e->stack_bar) {     // group counters of the fused residual stack: zero between launches (re-armed in-kernel)
+        void* q = nullptr;
+        const size_t nb = (size_t)(2 * dr_engine::STACK_GROUPS + 4 + 1024) * sizeof(unsigned);
+        HIPCHK(e, hipMalloc(&q, nb));
+        HIPCHK(e, hipMemset(q, 0, nb));
+        e->stack_bar = (unsigned*)q;
+        e->stack_err = e->stack_bar + 2 * dr_engine::STACK_GROUPS;
+        e->stack_xid = e->stack_err + 4;                      // one word per block (<= 1024 CUs)
+        void* d = nullptr;
+        HIPCHK(e, hipMalloc(&d, 128 * sizeof(long long)));
+        HIPCHK(e, hipMemset(d, 0, 128 * sizeof(long long)));
+        e->stack_dbg = (long long*)d;
+        hipDeviceProp_t prop;
+        HIPCHK(e, hipGetDeviceProperties(&prop, e->cfg.device));
+        e->n_cus = prop.multiProcessorCount;
+    }
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by
         // the same GEMM kernel; result d_dtab[t][l][c].
@@ -905,7 +1025,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     if (!e || !d_wav) return fail(e, DR_EINVAL, "null argument");
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     Range range("dr_frontend: mel + conditioner projections");
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     hipStream_t st = (hipStream_t)stream;
     const int N = e->cfg.n_fft, hop = e->cfg.hop_length, pad = N / 2;
     if (B <= 0 || L <= pad || T_roll <= 0) return fail(e, DR_EINVAL, "bad front-end shape B=%d L=%d T=%d", B, L, T_roll);
@@ -977,6 +1097,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
 
 int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond, float* d_x0_out, void* stream) {
     if (!e || !d_x || !d_x0_out) return fail(e, DR_EINVAL, "null argument");
+    DeviceGuard guard(e->cfg.device);
     const int sampler = cond == DR_COND_UNCOND ? DR_SAMPLER_GENERATION_DDPM_X0 : DR_SAMPLER_DDPM_X0;
     int rc = check_ready(e, sampler, B, T);
     if (rc) return rc;
@@ -988,6 +1109,7 @@ int dr_forward(dr_engine* e, const float* d_x, int B, int T, int t, int cond, fl
 int dr_forward_steps(dr_engine* e, const float* d_x, int B, int T, const int32_t* host_t, int cond, float* d_x0_out,
                      void* stream) {
     if (!e || !d_x || !d_x0_out || !host_t) return fail(e, DR_EINVAL, "null argument");
+    DeviceGuard guard(e->cfg.device);
     const int sampler = cond == DR_COND_UNCOND ? DR_SAMPLER_GENERATION_DDPM_X0 : DR_SAMPLER_DDPM_X0;
     int rc = check_ready(e, sampler, B, T);
     if (rc) return rc;
@@ -1011,6 +1133,7 @@ int dr_forward_steps(dr_engine* e, const float* d_x, int B, int T, const int32_t
 int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, int t, float w, uint64_t seed,
             int first_sample, void* stream) {
     if (!e || !d_x) return fail(e, DR_EINVAL, "null argument");
+    DeviceGuard guard(e->cfg.device);
     int rc = check_ready(e, sampler, B, T);
     if (rc) return rc;
     if (t < 0 || t >= e->S) return fail(e, DR_EINVAL, "step %d out of range", t);
@@ -1023,6 +1146,7 @@ int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, 
 int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, float w, uint64_t seed,
               int first_sample, int use_graph, void* stream) {
     if (!e || !d_x) return fail(e, DR_EINVAL, "null argument");
+    DeviceGuard guard(e->cfg.device);
     int rc = check_ready(e, sampler, B, T);
     if (rc) return rc;
     int NB, n_cond;
@@ -1078,7 +1202,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
 int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end, void* stream) {
     if (!e || !d_roll || !d_note_end) return fail(e, DR_EINVAL, "null argument");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     HIPCHK(e, launch_note_runs(d_roll, d_note_end, B, T, threshold, (hipStream_t)stream));
     return DR_OK;
 }
@@ -1087,7 +1211,7 @@ int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, siz
                     int64_t* host_counts, void* stream) {
     if (!e || !d_pred || !d_label || !host_counts) return fail(e, DR_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     if (!e->d_counts) {
         void* q = nullptr;
         HIPCHK(e, hipMalloc(&q, 3 * sizeof(unsigned long long)));
@@ -1122,7 +1246,7 @@ int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, cons
 
 int dr_profile_enable(dr_engine* e, int on) {
     if (!e) return DR_EINVAL;
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     e->prof = on != 0;
     if (e->prof && e->prof_events.empty()) {
         const size_t n = (size_t)e->S * e->L;
@@ -1135,6 +1259,7 @@ int dr_profile_enable(dr_engine* e, int on) {
 
 int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset) {
     if (!e) return DR_EINVAL;
+    DeviceGuard guard(e->cfg.device);
     HIPCHK(e, hipDeviceSynchronize());
     for (size_t i = 0; i < e->prof_used; ++i) {
         float ms = 0.f;
@@ -1149,13 +1274,62 @@ int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset
     return DR_OK;
 }
 
+int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double* total_flops, char* name, size_t name_len,
+                       int reset) {
+    if (!e) return DR_EINVAL;
+    const double fl = e->prof_flops;
+    int rc = dr_profile_read(e, launches, total_ms, reset);
+    if (rc) return rc;
+    if (total_flops) *total_flops = fl;
+    if (name && name_len) {
+        snprintf(name, name_len, "%s", e->prof_name.c_str());
+    }
+    if (reset) e->prof_flops = 0.0;
+    return DR_OK;
+}
+
+int dr_set_option(dr_engine* e, const char* name, int value) {
+    if (!e || !name) return fail(e, DR_EINVAL, "null argument");
+    const std::string n = name;
+    DeviceGuard guard(e->cfg.device);
+    auto drop_graph = [&]() {
+        (void)hipDeviceSynchronize();
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+        e->gkey = GraphKey{};
+    };
+    if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
+    if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
+    if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop_graph(); e->stack_dbg_on = value; return DR_OK; }
+    return fail(e, DR_ENAME, "unknown option '%s'", name);
+}
+
+int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* ticks, int n_ticks) {
+    if (!e) return DR_EINVAL;
+    if (!e->stack_bar) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    DeviceGuard guard(e->cfg.device);
+    HIPCHK(e, hipDeviceSynchronize());
+    unsigned flag = 0;
+    HIPCHK(e, hipMemcpy(&flag, e->stack_err, sizeof flag, hipMemcpyDeviceToHost));
+    if (timed_out) *timed_out = (int32_t)flag;
+    if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
+        HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(2 * dr_engine::STACK_GROUPS + 4) * sizeof(unsigned)));
+    }
+    if (ticks && n_ticks > 0) {
+        long long h[128];
+        HIPCHK(e, hipMemcpy(h, e->stack_dbg, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_ticks && i < 128; ++i) ticks[i] = h[i];
+    }
+    return DR_OK;
+}
+
 int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, void* stream) {
     if (!e) return DR_EINVAL;
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (layer < 0 || layer >= e->L || t < 0 || t >= e->S || n_cond < 0 || n_cond > NB)
         return fail(e, DR_EINVAL, "bad argument");
     if (n_cond > 0 && (e->fe_B < n_cond || e->fe_T != T)) return fail(e, DR_ESTATE, "dr_frontend needed for n_cond > 0");
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     int rc = ensure_workspace(e, NB, T);
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
@@ -1190,7 +1364,7 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     if (!e) return DR_EINVAL;
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (layer < 0 || layer >= e->L) return fail(e, DR_EINVAL, "bad argument");
-    HIPCHK(e, hipSetDevice(e->cfg.device));
+    DeviceGuard guard(e->cfg.device);
     int rc = ensure_workspace(e, NB, T);
     if (rc) return rc;
     const int Cp = e->Cp, P = Cp / 4;
@@ -1232,6 +1406,7 @@ int dr_set_precision(dr_engine* e, int mode) {
     if (!e) return DR_EINVAL;
     if (mode != DR_PRECISION_F32 && mode != DR_PRECISION_BF16X3) return fail(e, DR_EINVAL, "unknown precision mode %d", mode);
     if (mode != e->prec) {
+        DeviceGuard guard(e->cfg.device);     // the graph may still be executing on the ENGINE's device
         (void)hipDeviceSynchronize();
         if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
@@ -1243,6 +1418,7 @@ int dr_set_precision(dr_engine* e, int mode) {
 
 int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks) {
     if (!e || !e->dbg_ticks) return fail(e, DR_ESTATE, "no dr_bench_layer launch yet");
+    DeviceGuard guard(e->cfg.device);
     long long h[16];
     HIPCHK(e, hipDeviceSynchronize());
     HIPCHK(e, hipMemcpy(h, e->dbg_ticks, sizeof h, hipMemcpyDeviceToHost));

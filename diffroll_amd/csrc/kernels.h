@@ -82,6 +82,9 @@ struct GemmArgs {
     size_t ws_floats, ws_cnt_n;
     int ksplit;              // set by the launcher
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
+    int wt_store;            // fused residual stack only (COH bodies): 1 = the tensors handed to other workgroups are
+                             // stored write-through (sc1), 0 = plain stores (every workgroup of the group shares one
+                             // XCD's L2, verified at run time)
 };
 
 // gemm_kernel: block tile = 128 packed rows x 64*NI frames (NI in {1, 2}), 512 threads (4 consumer + 4 producer
@@ -95,6 +98,41 @@ hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 // (NW in {2,3,4,5}), 256 threads
 hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
+
+// ---------------------------------------------------------------------------------------------
+// Fused residual stack: ONE persistent launch runs a range of the 2L phases of the residual layers
+// (phase 2l = dilated conv + conditioner + gate of layer l, phase 2l+1 = its 1x1 + residual / skip), instead of
+// one launch per phase.  grid = (samples x frame tiles x M tiles) <= the number of CUs, every block owns the same
+// (M tile, frame tile) in every phase; the blocks of one sample (= one clip evaluation: M tiles x its frame tiles)
+// form a GROUP that synchronises on a device counter between phases - nothing is exchanged between groups, so
+// there is no grid-wide barrier.  See stack_kernel in kernels.hip.
+// ---------------------------------------------------------------------------------------------
+constexpr int DR_STACK_MAX_LAYERS = 30;
+struct StackLayer {
+    const float *conv_w, *conv_b, *conv_b2;   // packed dilated-conv weights; bias of samples < n_cond / >= n_cond
+    const float *cond, *cond2;                // conditioner tensors of this layer (see GemmArgs)
+    const float *out_w, *out_b;               // packed 1x1 weights / bias
+    int dil, pad_;
+};
+struct StackArgs {
+    float *h, *hd, *g, *skip;                 // P4 activations [NB][Cp/4][T][4]
+    const float* d2;                          // step-embedding rows: layer l+1's row is d2 + (l + 1) * Cp (+ tsel[b] * d2_ts)
+    const int* tsel;
+    long d2_ts;
+    const float* zero;                        // device zero vector (never-null operands)
+    int NB, T, Cp, taps, n_cond, L;
+    long c_bs;
+    int p0, p1;                               // phases [p0, p1)
+    int xcd_n;                                // block -> (M tile, frame tile) mapping, as in gemm_kernel
+    int rs_off;                               // set by the launcher: LDS byte offset of the resident h / skip tile
+    unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)
+    unsigned* bar;                            // [groups][2] arrival / departure counters, all zero between launches
+    unsigned* err;                            // set to 1 if a barrier wait ran into its spin bound (never in a healthy run)
+    long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
+    StackLayer layer[DR_STACK_MAX_LAYERS];
+};
+// NI in {1, 2}: 64 / 128 frames per block.  The caller guarantees NB * ceil(T / (64 NI)) * (Cp / 64) <= #CUs.
+hipError_t launch_stack(const StackArgs& s, int NI, int max_dil, hipStream_t st);
 
 // Per-call scalars of the update that must not be baked into a captured graph: the chain graph reads them from
 // this device block, which a one-thread kernel rewrites (stream-ordered) before every graph launch - a new

@@ -117,6 +117,21 @@ DR_DEVINL void sgb_spread() {
     }
 }
 DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// 16-byte store of one P4 quad.  COH = 1: write-through (sc1) - the line leaves this XCD's L2 for memory, where
+// every other XCD's sc1 load finds it; the instruction sits in inline asm (no builtin takes a flat pointer with a
+// cache policy), so the COMPILER does not count it: every wave drains with an explicit s_waitcnt vmcnt(0)
+// before it signals (stack_kernel's group barrier).  The trailing s_nop covers the store-data hazard.
+template <int COH>
+DR_DEVINL void store_f4(float* dst, const float4 v, const int write_through) {
+    if constexpr (COH) {
+        if (write_through) {           // wave-uniform (a kernel-wide mode)
+            const f32x4 d = {v.x, v.y, v.z, v.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");
+            return;
+        }
+    }
+    *reinterpret_cast<float4*>(dst) = v;
+}
 DR_DEVINL float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // Gate of the residual block (model/diffwave.py:146-147) on the hardware transcendentals: v_exp_f32 (2^x) and
 // v_rcp_f32, ~1 ulp each.  sigmoid(u) = 1 / (1 + 2^(-u log2 e)); tanh(v) = 1 - 2 / (2^(2 v log2 e) + 1), which
@@ -156,9 +171,12 @@ DR_DEVINL float gatef_(float u, float v) {
 //   PREC = 1 ("S3"): the X input and the weights are split-bf16 (see above): X tile rows are
 //   [(sub*2 + g)*6 + piece*2 + kq] (16 channels per group g, 8 per kq half), the consumers run 6
 //   v_mfma_f32_32x32x16_bf16 per (group, row tile, frame tile) instead of 8 fp32 MFMAs per 16 channels.
-template <int NI, int KS, int EPI, int PREC>
-__global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+//   COH = 1 (the fused residual-stack kernel only): the tensors this body exchanges with OTHER workgroups of the
+//   same launch - its X input (hd) and its EPI_GATE output (g) - are read with sc1 loads and written with sc1
+//   (write-through) stores, the placement-independent hand-off form of MI355X_MICROARCH.md "inter-workgroup
+//   visibility"; everything else (weights, biases, conditioner: written before the launch) stays plain.
+template <int NI, int KS, int EPI, int PREC, int COH>
+DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
     constexpr int BN = 64 * NI;
     constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
     // Consumer wave arrangement: 4 (M) x 1 (N) - every wave owns 32 distinct rows x all 64*NI frames of the
@@ -187,26 +205,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     // (Holding it in 64 prefetch VGPRs instead cost the compiler the B-fragment software pipelining.)
     float4* Rs = Xs + 2 * XP * FW;
 
-    // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
-    // one 128-row weight panel, which then stays resident in that XCD's private L2.
-    // xcd_n != 0 (X-heavy 1x1 GEMMs: small weights, big activations): the 8 M tiles of one frame tile
-    // run on the SAME XCD instead, so the X tile is fetched from HBM once per XCD and hits L2 for the
-    // other M tiles, while the (small) weight matrix is L2-resident in every XCD.
-    // Split-K (ksplit > 1, under-filled launches only: few samples / narrow GEMMs): ksplit blocks share
-    // one output tile, each contracts a contiguous range of the K chunks; see the reduction below.
-    int mt, nt, ks;
-    if (a.xcd_n) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        mt = idx % a.MT;
-        const int rest = idx / a.MT;
-        ks = rest % a.ksplit;
-        nt = (rest / a.ksplit) * 8 + xcd;
-    } else {
-        mt = blockIdx.x % a.MT;
-        const int rest = blockIdx.x / a.MT;
-        ks = rest % a.ksplit;
-        nt = rest / a.ksplit;
-    }
+    // (mt, nt, ks) = this block's M tile, frame tile and K split: chosen by the caller (gemm_kernel below)
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
@@ -247,7 +246,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
                 float4* dst = Xs + (((chunk - c0) & 1) * XP + pl) * FW + seg * 64;
-                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
+                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, COH ? 16 : 0);
             }
         };
         if constexpr (EPI == EPI_RES_SKIP) {
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     if (a.ksplit > 1) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         constexpr int WQ = NW * 4;                                   // float4 per lane per wave region
-        constexpr int COH = 17;                                      // buffer cache policy: sc0 | sc1
+        constexpr int WSCOH = 17;                                    // buffer cache policy: sc0 | sc1
         const int tile = nt * a.MT + mt;
         const __amdgpu_buffer_rsrc_t wsr =
             __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, 0, (unsigned)(a.ws_floats * 4), 0x00020000);
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const u32x4 v = {__float_as_uint(acc[0][ni][4 * q]), __float_as_uint(acc[0][ni][4 * q + 1]),
                                  __float_as_uint(acc[0][ni][4 * q + 2]), __float_as_uint(acc[0][ni][4 * q + 3])};
-                __builtin_amdgcn_raw_buffer_store_b128(v, wsr, base + ks * sstride + (ni * 4 + q) * 1024, 0, COH);
+                __builtin_amdgcn_raw_buffer_store_b128(v, wsr, base + ks * sstride + (ni * 4 + q) * 1024, 0, WSCOH);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // partials are out before the ticket is drawn
         unsigned ticket = 0;
@@ -552,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int i = 0; i < WQ; ++i)
-                    v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + (sp0 + u) * sstride + i * 1024, 0, COH);
+                    v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + (sp0 + u) * sstride + i * 1024, 0, WSCOH);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -660,7 +659,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
                         store_s3_quad(a.Y + (long)be * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
                     } else {
                         float* dst = a.Y + (long)be * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                        store_f4<COH>(dst, make_float4(o[0], o[1], o[2], o[3]), a.wt_store);
                     }
                 } else {
     #pragma unroll
@@ -733,6 +732,32 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     }
 }
 
+template <int NI, int KS, int EPI, int PREC>
+__global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
+    // one 128-row weight panel, which then stays resident in that XCD's private L2.
+    // xcd_n != 0 (X-heavy 1x1 GEMMs: small weights, big activations): the 8 M tiles of one frame tile
+    // run on the SAME XCD instead, so the X tile is fetched from HBM once per XCD and hits L2 for the
+    // other M tiles, while the (small) weight matrix is L2-resident in every XCD.
+    // Split-K (ksplit > 1, under-filled launches only: few samples / narrow GEMMs): ksplit blocks share
+    // one output tile, each contracts a contiguous range of the K chunks; see the reduction in gemm_body.
+    int mt, nt, ks;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        const int rest = idx / a.MT;
+        ks = rest % a.ksplit;
+        nt = (rest / a.ksplit) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        const int rest = blockIdx.x / a.MT;
+        ks = rest % a.ksplit;
+        nt = rest / a.ksplit;
+    }
+    gemm_body<NI, KS, EPI, PREC, 0>(a, smem, mt, nt, ks);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pointwise (1x1) GEMM with BOTH operands straight from L2: the 1x1 output projection + residual / skip
 // update (model/diffwave.py:149-151, :680).  A 1x1 GEMM has no tap reuse, so staging X through LDS buys
@@ -744,24 +769,26 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 // issues 16*NW MFMAs.  No LDS, no barriers, no producers.  Frames beyond T are clamped (their columns are
 // never written).
 // ---------------------------------------------------------------------------------------------
-template <int NW>     // 32-frame MFMA tiles per wave: block = 128 rows x 32*NW frames
-__global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
+//   COH = 1 (fused residual-stack kernel): the second output Y2 (hd, read by other workgroups of the same launch)
+//   is stored write-through (sc1) unless a.wt_store == 0; X (g, written by other workgroups) is read with plain
+//   loads AFTER an agent-scope acquire in the preceding group barrier; the read-modify-write tiles h and skip
+//   belong to this workgroup alone for the whole launch.
+//   Run by waves 0-3 of the block (wave = wave index); mt / nt = M tile and frame tile.
+//   RLDS = 1 (fused kernel; Rs = the tile): the block's read-modify-write tile (its 128 rows of h / skip x BN frames,
+//   [32 planes][BN] float4) is RESIDENT IN LDS for the whole launch instead of being re-read from and re-written
+//   to global memory by every layer: the epilogue reads and updates it there (no operand registers are held
+//   across the last K steps - with them the fused kernel spilled), only hd goes to global.
+template <int NW, int COH, int RLDS>     // 32-frame MFMA tiles per wave: block = 128 rows x 32*NW frames
+DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int wave, float4* Rs = nullptr) {
     constexpr int BN = 32 * NW;
+    // X loads are PLAIN also in the fused kernel: the four waves of a block read the same B fragments, and only
+    // the CU's L1 turns that into one L2 request instead of four (measured: with L1-bypassing sc1 loads the phase
+    // ran 2x slower) - the fused kernel therefore invalidates the L1 once, in the barrier before this phase.
+    constexpr int XAUX = 0;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hi = lane >> 5;
     const long long tick0 = a.dbg ? clock64() : 0;
 
-    int mt, nt;
-    if (a.xcd_n) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        mt = idx % a.MT;
-        nt = (idx / a.MT) * 8 + xcd;
-    } else {
-        mt = blockIdx.x % a.MT;
-        nt = blockIdx.x / a.MT;
-    }
-    mt += a.mt0;    // launches over a sub-range of the M tiles (the last layer only needs its skip rows)
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
@@ -798,7 +825,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int ni = 0; ni < NW; ++ni)
-                o.v[g][ni] = asf4(__builtin_amdgcn_raw_buffer_load_b128(xr, xvo[ni], (slab * 8 + g * 2) * xps, 0));
+                o.v[g][ni] = asf4(__builtin_amdgcn_raw_buffer_load_b128(xr, xvo[ni], (slab * 8 + g * 2) * xps, XAUX));
         return o;
     };
 
@@ -841,13 +868,14 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
     auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
     const int rowb = mt * 128 + wave * 32 + 4 * hi;           // + 8q
     const bool res_rows = rowb < a.y_rows;                     // wave-uniform (y_rows is a multiple of 64)
-    float4 ebias[4], ed2[4], eop[NW][4];
+    float4 ebias[4], ed2[4], eop[RLDS ? 1 : NW][4];
     auto load_epilogue = [&]() {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             ebias[q] = *reinterpret_cast<const float4*>(a.bias + rowb + 8 * q);
             ed2[q] = *reinterpret_cast<const float4*>(a.d2 + (a.tsel ? (long)a.tsel[b] * a.d2_ts : 0) + min(rowb + 8 * q, a.y_rows - 4));
         }
+        if constexpr (RLDS) return;                                     // the tile waits in LDS
         const float* base = res_rows ? a.Y + (long)b * a.y_bs + (long)(rowb >> 2) * a.y_ps
                                      : a.skip + (long)b * a.s_bs + (long)((rowb - a.y_rows) >> 2) * a.T * 4;
         const long qs = res_rows ? 2 * a.y_ps : (long)2 * a.T * 4;      // 8 rows = 2 planes further
@@ -864,8 +892,12 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
     for (; slab < pre; slab += 2) {
         step(std::false_type{}, slab);
         step(std::true_type{}, slab + 1);
+        if (a.dbg && slab == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[2] = clock64() - tick0;   // first two steps done
     }
-    load_epilogue();
+    if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[3] = clock64() - tick0;                    // before the RMW-tile request
+    // (RLDS: only the bias / step-embedding rows are left to load - 8 L2-hot float4 per lane, requested after the
+    // loop: holding them across the last K steps is what pushed the fused kernel over its register budget)
+    if constexpr (!RLDS) load_epilogue();
     __builtin_amdgcn_sched_barrier(0);
     for (; slab + 2 <= NS; slab += 2) {
         step(std::false_type{}, slab);
@@ -873,6 +905,7 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
     }
     if (slab < NS) step(std::false_type{}, slab);
     const long long tick1 = a.dbg ? clock64() : 0;
+    if constexpr (RLDS) load_epilogue();
 
 #pragma unroll
     for (int ni = 0; ni < NW; ++ni) {
@@ -884,12 +917,16 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
             float v[4], bb[4], pv[4], o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[ni][4 * q + e];
-            f4arr(ebias[q], bb); f4arr(eop[ni][q], pv);
+            float4* rs = Rs + (wave * 8 + 2 * q + hi) * BN + ni * 32 + r;    // this quad in the LDS tile (RLDS)
+            f4arr(ebias[q], bb);
+            if constexpr (RLDS) f4arr(*rs, pv);
+            else f4arr(eop[ni][q], pv);
             if (res_rows) {
                 float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (RLDS) *rs = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
                 if (a.Y2) {
                     float dd[4];
                     f4arr(ed2[q], dd);
@@ -898,14 +935,15 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
                         store_s3_quad(a.Y2 + (long)b * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
                     } else {
                         float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                        *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+                        store_f4<COH>(dst2, make_float4(o2[0], o2[1], o2[2], o2[3]), a.wt_store);
                     }
                 }
             } else {
                 float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
-                *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (RLDS) *rs = make_float4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -913,6 +951,22 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
         a.dbg[0] = tick1 - tick0;
         a.dbg[1] = clock64() - tick0;
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int mt, nt;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        nt = (idx / a.MT) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        nt = blockIdx.x / a.MT;
+    }
+    mt += a.mt0;    // launches over a sub-range of the M tiles (the last layer only needs its skip rows)
+    pw_body<NW, 0, 0>(a, mt, nt, wave);
 }
 
 template <int NW>
@@ -937,6 +991,215 @@ hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s) {
         case 5: return launch_pw_t<5>(a, s);
     }
     return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused residual stack (model/diffwave.py:134-151 x residual_layers, the loop at :678-681): a persistent kernel
+// that walks a range of the 2L phases - phase 2l = gemm_body<EPI_GATE> of layer l (dilated conv + conditioner +
+// gate -> g), phase 2l+1 = pw_body of layer l (1x1 -> h, hd = h + d_{l+1}, skip) - with every block keeping its
+// (M tile, frame tile) for the whole launch.  Same device code, same MFMA order, same epilogue arithmetic as the
+// per-phase launches: results are bit-identical to them.
+//
+// Why it is legal without a grid barrier: a clip evaluation never reads another clip evaluation's activations
+// (no cross-sample operation on the path), so only the blocks of ONE sample - its M tiles x its
+// frame tiles, the GROUP - exchange data: g (written per M tile, read by every 1x1 block of the group) and hd
+// (written by the residual-row blocks, read with its halo by every conv block of the group).  h and skip tiles
+// are read-modify-written by the same block in every layer.  Between phases the group meets at a counter.
+//
+// Hand-off form (MI355X_MICROARCH.md "inter-workgroup visibility", valid under any block -> XCD placement):
+// producers store g / hd write-through (sc1) -> every wave drains (s_waitcnt vmcnt(0)) -> __syncthreads() ->
+// one lane arrives on the group counter (relaxed, agent scope) and polls it -> [one agent-scope acquire when the
+// next phase reads with plain loads] -> __syncthreads() -> consumers read hd with sc1 LDS-DMA loads (L1 bypassed)
+// and g with plain loads (L1 freshly invalidated); the XCD's L2 is never left with a stale copy: a write-through
+// store drops / invalidates it.  Counters are re-armed by the last block of the group to leave the launch, so a
+// replayed graph needs no memset node.  Spins are bounded: a wait that runs into the bound sets *err and
+// carries on (wrong data, but no hung queue).
+// ---------------------------------------------------------------------------------------------
+template <bool ACQUIRE>
+DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave: its stores (incl. the asm sc1 ones) are out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            // ~1 s of polling (a phase lasts < 1 ms), or another wait already gave up: flag it and carry on
+            if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        // ONE agent-scope acquire per block (buffer_inv sc1: drops this CU's L1 lines) after the match, so that the
+        // PLAIN loads of the next phase cannot hit a line cached before the producers rewrote it
+        if constexpr (ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+
+template <int NI>
+__global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // The arguments are read through the kernarg segment pointer (constant address space: scalar loads at the
+    // point of use).  Indexing the by-value struct with the run-time layer index made the compiler copy it to
+    // scratch, after which every per-layer pointer lived in VGPRs and each buffer load was wrapped in a
+    // waterfall loop.
+    (void)s_by_value;
+    typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
+    const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+#define s (*sp)
+    constexpr int BN = 64 * NI;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int MT = s.Cp >> 6;
+    const int tps = (s.T + BN - 1) / BN;
+    const unsigned gsize = (unsigned)(MT * tps);          // blocks per group
+    int mt, nt, grp, member;
+    if (s.xcd_n) {       // all blocks of a group on one XCD (block b is dispatched to XCD b % 8): the group shares an L2
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        member = idx % (int)gsize;
+        grp = (idx / (int)gsize) * 8 + xcd;
+    } else {             // one weight panel per XCD, as the per-phase conv launches
+        member = blockIdx.x % (int)gsize;
+        grp = blockIdx.x / (int)gsize;
+    }
+    mt = member % MT;                                     // sample (clip evaluation) grp = barrier group
+    nt = grp * tps + member / MT;
+    unsigned* ctr = s.bar + 2 * grp;
+    const long act_bs = (long)s.Cp * s.T;
+    const int P = s.Cp >> 2;
+    unsigned episode = 0;
+    // Store mode of the tensors handed to other workgroups (g, hd).  Until the group has PROVED that all its
+    // blocks run on one XCD (same L2) they are stored write-through (sc1), which is valid under any placement;
+    // each block publishes its XCC id before the first barrier and compares the group's ids after it - when they
+    // all agree the remaining phases use plain stores (the lines stay in the shared L2, where the sc1 loads of the
+    // consumers find them: ~2x faster 1x1 phases).  Placement is never ASSUMED.
+    // The block's read-modify-write tile - its 128 packed rows of the 1x1 output (h rows for the residual M tiles,
+    // skip rows for the others) x its BN frames - lives in LDS for the whole launch: [32 planes][BN] float4 behind
+    // the conv's X tiles.  Loaded here (LDS-DMA, frames >= T read 0), written back after the last phase.
+    float4* Rs = reinterpret_cast<float4*>(smem + s.rs_off);
+    const int b_ = nt / tps, t0_ = (nt % tps) * BN;
+    auto tile_plane = [&](int pl, bool& is_res) -> float* {     // global address of plane pl (4 rows) of the tile, frame 0
+        const int row0 = mt * 128 + pl * 4;
+        is_res = row0 < s.Cp;
+        return is_res ? s.h + (long)b_ * act_bs + (long)(row0 >> 2) * s.T * 4
+                      : s.skip + (long)b_ * act_bs + (long)((row0 - s.Cp) >> 2) * s.T * 4;
+    };
+    {
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        const int lane = threadIdx.x & 63;
+        for (int i = wave; i < 32 * NI; i += 8) {
+            const int pl = i / NI, seg = i - pl * NI;
+            bool is_res;
+            const float* src = tile_plane(pl, is_res);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)s.T * 16u, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0_ + seg * 64 + lane) * 16, 0, 0, 0);
+        }
+        // (the first group barrier - or the end of a one-phase launch - drains these loads: s_waitcnt vmcnt(0)
+        // + __syncthreads(); a launch that STARTS with a 1x1 phase waits right here)
+        if (s.p0 & 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    int wt_store = 1;
+    if (threadIdx.x == 0) {
+        unsigned my_xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+        __hip_atomic_store(s.xid + (long)grp * gsize + member, my_xcc & 0xfu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+#pragma unroll 1
+    for (int p = s.p0; p < s.p1; ++p) {
+        const int l = p >> 1;
+        const __attribute__((address_space(4))) StackLayer& ly = sp->layer[l];
+        if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[p - s.p0] = clock64();
+        GemmArgs a{};
+        a.d2 = s.zero;
+        a.wt_store = wt_store;
+        a.MT = MT; a.NB = s.NB; a.T = s.T; a.alpha = 1.f; a.ksplit = 1;
+        a.x_bs = act_bs; a.x_ps = (long)s.T * 4; a.x_fs = 4; a.x_planes = P; a.kchunks = s.Cp >> 5;
+        a.y_bs = act_bs; a.y_ps = (long)s.T * 4; a.y_fs = 4; a.y_rows = s.Cp;
+        if ((p & 1) == 0) {
+            a.Wp = ly.conv_w; a.bias = ly.conv_b; a.bias2 = ly.conv_b2;
+            a.X = s.hd; a.taps = s.taps; a.dil = ly.dil;
+            a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
+            a.Y = s.g;
+            if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
+            gemm_body<NI, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
+        } else {
+            a.Wp = ly.out_w; a.bias = ly.out_b;
+            a.X = s.g; a.taps = 1; a.dil = 1;
+            a.Y = s.h;
+            const bool last = (l + 1 == s.L);
+            if (!last) {     // hd = h + d_{l+1}: the next dilated conv's input
+                a.Y2 = s.hd; a.y2_bs = act_bs;
+                a.d2 = s.d2 + (long)(l + 1) * s.Cp; a.tsel = s.tsel; a.d2_ts = s.d2_ts;
+            }
+            a.skip = s.skip; a.s_bs = act_bs; a.skip_init = (l == 0);
+            // the last layer's residual output is never read (model/diffwave.py:678-682): its residual-only M
+            // tiles have nothing to do
+            const bool idle = last && mt < (s.Cp >> 7);
+            if (s.dbg && p + 3 == s.p1) a.dbg = s.dbg + 96;       // second-to-last 1x1 phase (block 0 works in it)
+            if (wave < 4 && !idle) pw_body<2 * NI, 1, 1>(a, mt, nt, wave, Rs);
+        }
+        if (p + 1 < s.p1) {
+            // the phase after an even one is a 1x1: its plain g loads need the acquire; a conv phase reads hd
+            // with L1-bypassing sc1 LDS-DMA loads and needs none
+            if ((p & 1) == 0) group_barrier<true>(ctr, ++episode * gsize, s.err);
+            else group_barrier<false>(ctr, ++episode * gsize, s.err);
+            if (episode == 1) {      // every block of the group has published its XCC id: one L2 for all of them?
+                unsigned mine;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
+                mine &= 0xfu;
+                int same = 1;
+                for (unsigned i = 0; i < gsize; ++i)
+                    same &= (__hip_atomic_load(s.xid + (long)grp * gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
+                wt_store = __builtin_amdgcn_readfirstlane(same ? 0 : 1);     // wave-uniform (every lane read the same words)
+            }
+        }
+    }
+    if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[s.p1 - s.p0] = clock64();
+    // write the resident tile back: skip always (the skip projection reads it next), h only when layers remain
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int lane = threadIdx.x & 63;
+        for (int i = wave; i < 32 * NI; i += 8) {
+            const int pl = i / NI, seg = i - pl * NI;
+            bool is_res;
+            float* dst = tile_plane(pl, is_res);
+            const int t = t0_ + seg * 64 + lane;
+            if (t < s.T && (!is_res || s.p1 < 2 * s.L))
+                *reinterpret_cast<float4*>(dst + (long)t * 4) = Rs[pl * BN + seg * 64 + lane];
+        }
+    }
+    // leave: the last block of the group to get here re-arms both counters for the next launch (nobody of this
+    // group polls any more: everyone passed its last barrier before arriving here)
+    if (threadIdx.x == 0) {
+        const unsigned left = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (left == gsize - 1) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#undef s
+}
+
+hipError_t launch_stack(const StackArgs& s, int NI, int max_dil, hipStream_t st) {
+    if (NI != 1 && NI != 2) return hipErrorInvalidValue;
+    if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
+    const int BN = 64 * NI, tps = (s.T + BN - 1) / BN, MT = s.Cp >> 6;
+    const size_t xl = gemm_lds_bytes(NI, 1, s.taps, max_dil, 0, EPI_GATE);   // the conv's X tiles ...
+    const size_t lds = xl + (size_t)32 * BN * 16;                            // ... + the resident h / skip tile
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    StackArgs b = s;
+    b.rs_off = (int)xl;
+    const int NT = s.NB * tps;
+    if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;            // the group-per-XCD mapping deals groups round-robin to 8 XCDs
+    const dim3 grid((unsigned)(MT * NT));
+    if (NI == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
+    else hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1306,6 +1569,8 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return init_gemm16();
 }
 

@@ -43,23 +43,53 @@ def gather_rolls(local: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def unpad_gathered(full: torch.Tensor, n_total: int, world_size: int) -> torch.Tensor:
+    """Rank-major gather of shards padded to the largest shard -> the n_total real samples, in order."""
+    mx = (n_total + world_size - 1) // world_size
+    parts = []
+    for r in range(world_size):
+        lo, hi = shard_bounds(n_total, r, world_size)
+        parts.append(full[r * mx: r * mx + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def pad_shard(local: torch.Tensor, n_total: int, world_size: int) -> torch.Tensor:
+    """Zero-pad a shard_bounds() shard to the size of the largest one (what every rank contributes to the gather)."""
+    mx = (n_total + world_size - 1) // world_size
+    pad = mx - local.shape[0]
+    if pad:
+        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
+    return local
+
+
 def gather_rolls_uneven(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """As gather_rolls for shard_bounds() partitions whose sizes differ by one: pad to the largest
     shard, gather, and drop the padding."""
     d = _dist()
-    if d is None or d.get_world_size(group) == 1:
+    if d is None:
         return local
-    ws = d.get_world_size(group)
-    mx = (n_total + ws - 1) // ws
-    pad = mx - local.shape[0]
-    if pad:
-        local = torch.cat([local, local.new_zeros((pad,) + tuple(local.shape[1:]))], 0)
-    full = gather_rolls(local, group)
-    parts = []
-    for r in range(ws):
-        lo, hi = shard_bounds(n_total, r, ws)
-        parts.append(full[r * mx: r * mx + (hi - lo)])
-    return torch.cat(parts, 0)
+    ws = d.get_world_size(group)          # a 1-rank group still goes through the collective
+    return unpad_gathered(gather_rolls(pad_shard(local, n_total, ws), group), n_total, ws)
+
+
+def sample_shard(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], noise: Optional[torch.Tensor],
+                 seed: int, rank: int, world_size: int) -> torch.Tensor:
+    """The part of sample_sharded one rank computes: the chain of its contiguous shard of the GLOBAL batch,
+    returned as (b_local, 1, T', 88) on the engine's device (b_local may be 0).  Philox noise is keyed by the
+    global sample index (first_sample = lo), so the rolls do not depend on the world size."""
+    B = x_T.shape[0]
+    lo, hi = shard_bounds(B, rank, world_size)
+    wav = None if waveform is None else waveform[lo:hi]
+    z = None if noise is None else noise[:, lo:hi]
+    if hi > lo:
+        roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
+        return roll
+    # more ranks than clips: an empty shard with the frame count the other ranks will produce
+    T = x_T.shape[2]
+    hop = getattr(model.engine, "hop_length", None)
+    if waveform is not None and hop:
+        T = min(T, waveform.shape[-1] // hop + 1)       # trim_spec_roll, model/diffwave.py:30-39
+    return torch.zeros((0, 1, T, x_T.shape[3]), dtype=torch.float32, device=model.engine.device)
 
 
 def sample_sharded(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], noise: Optional[torch.Tensor] = None,
@@ -68,16 +98,17 @@ def sample_sharded(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], n
     (S,B,1,T,88)); each runs its contiguous shard and all ranks return the full (B,1,T',88) result.
     Philox noise is keyed by the global sample index, so the result does not depend on the world size."""
     rank, ws = world()
+    roll = sample_shard(model, x_T, waveform, noise, seed, rank, ws)
+    return gather_rolls_uneven(roll, x_T.shape[0], group)
+
+
+def sample_sharded_sequential(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor],
+                              noise: Optional[torch.Tensor] = None, seed: int = 0, world_size: int = 2) -> torch.Tensor:
+    """The world_size-rank job emulated on ONE device: every rank's sample_shard() is run in turn through the same
+    slicing / padding / un-padding code the collective path uses (the all-gather itself is the concatenation of
+    the padded shards in rank order).  Used by the GPU tests to hold the N-rank result to the unsharded one when
+    only one GPU is leased."""
     B = x_T.shape[0]
-    lo, hi = shard_bounds(B, rank, ws)
-    wav = None if waveform is None else waveform[lo:hi]
-    z = None if noise is None else noise[:, lo:hi]
-    if hi > lo:
-        roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
-    else:       # more ranks than clips: an empty shard with the frame count the other ranks will produce
-        T = x_T.shape[2]
-        hop = getattr(model.engine, "hop_length", None)
-        if waveform is not None and hop:
-            T = min(T, waveform.shape[-1] // hop + 1)       # trim_spec_roll, model/diffwave.py:30-39
-        roll = torch.zeros((0, 1, T, x_T.shape[3]), dtype=torch.float32, device=model.engine.device)
-    return gather_rolls_uneven(roll, B, group)
+    shards = [pad_shard(sample_shard(model, x_T, waveform, noise, seed, r, world_size), B, world_size)
+              for r in range(world_size)]
+    return unpad_gathered(torch.cat(shards, 0), B, world_size)

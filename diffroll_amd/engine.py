@@ -221,6 +221,26 @@ class Engine:
         self._check(self.lib.dr_profile_read(self.h, C.byref(n), C.byref(ms), 1 if reset else 0))
         return n.value, ms.value
 
+    def profile_read_ex(self, reset: bool = True):
+        """(launches, total_ms, algorithmic_flops, kernel_name) of the timed (dominant) kernel."""
+        n = C.c_int64(0)
+        ms = C.c_double(0.0)
+        fl = C.c_double(0.0)
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.dr_profile_read_ex(self.h, C.byref(n), C.byref(ms), C.byref(fl), buf, 256, 1 if reset else 0))
+        return n.value, ms.value, fl.value, buf.value.decode()
+
+    def set_option(self, name: str, value: int):
+        """'fused_stack' / 'fused_stack_xcd' / 'stack_ticks' (include/diffroll_amd.h: dr_set_option)."""
+        self._check(self.lib.dr_set_option(self.h, name.encode(), int(value)))
+
+    def stack_status(self, n_ticks: int = 0):
+        """(timed_out, ticks): synchronises; timed_out != 0 means a fused-kernel barrier hit its spin bound."""
+        flag = C.c_int32(0)
+        arr = (C.c_int64 * max(n_ticks, 1))()
+        self._check(self.lib.dr_stack_status(self.h, C.byref(flag), arr, int(n_ticks)))
+        return int(flag.value), [int(v) for v in arr[:n_ticks]]
+
     def bench_pointwise(self, layer: int, NB: int, T: int):
         with torch.cuda.device(self.device):
             self._check(self.lib.dr_bench_pointwise(self.h, layer, NB, T, self._stream()))

@@ -157,9 +157,18 @@ class ClassifierFreeDiffRoll(nn.Module):
             sample_rate=int(sa.get("sample_rate", 16000)), n_fft=int(sa.get("n_fft", 2048)),
             hop_length=int(sa.get("hop_length", 512)), f_min=float(sa.get("f_min", 0.0)),
             f_max=float(sa.get("f_max", 8000.0)))
-        for key in ("center", "normalized"):
-            if key in sa and not sa[key]:
-                raise NotImplementedError(f"spec_args.{key}=False is not supported (config/spec/mel.yaml)")
+        # The front-end kernels implement config/spec/mel.yaml: center=True and normalized=True.  torchaudio's own
+        # default for `normalized` is False, so a spec_args without the key would build a DIFFERENT front-end in the
+        # reference (log(x + 1e-6) then min-max does not cancel the window scale): the key must be present and true.
+        if not sa.get("center", True):
+            raise NotImplementedError("spec_args.center=False is not supported (config/spec/mel.yaml)")
+        if "normalized" not in sa:
+            raise NotImplementedError("spec_args.normalized is required and must be True (config/spec/mel.yaml:10): "
+                                      "torchaudio's default is False, which this front-end does not implement")
+        if not sa["normalized"]:
+            raise NotImplementedError("spec_args.normalized=False is not supported (config/spec/mel.yaml)")
+        # the remaining keys default to config/spec/mel.yaml's values (n_fft 2048, hop 512, f_max 8000, sr 16000),
+        # NOT to torchaudio's (400 / 200 / sr/2): the engine is built for the released configuration
         if sa.get("pad_mode", "reflect") != "reflect":
             raise NotImplementedError("only pad_mode='reflect' is supported (config/spec/mel.yaml)")
         # every other torchaudio MelSpectrogram argument must be at the value the front-end kernels implement
@@ -252,9 +261,13 @@ class ClassifierFreeDiffRoll(nn.Module):
     # ------------------------------------------------------------------ forward
     def _frontend(self, waveform: torch.Tensor, T_roll: int, inpainting_t, inpainting_f) -> torch.Tensor:
         eng = self.engine
-        key = (waveform.data_ptr(), tuple(waveform.shape), waveform._version, T_roll,
+        try:
+            version = waveform._version
+        except Exception:                      # inference-mode tensors do not track a version: never cached
+            version = None
+        key = (waveform.data_ptr(), tuple(waveform.shape), version, T_roll,
                tuple(inpainting_t) if inpainting_t else None, tuple(inpainting_f) if inpainting_f else None)
-        if key != self._fe_key:
+        if version is None or key != self._fe_key:
             self._fe_spec = eng.frontend(waveform, T_roll, inpainting_t, inpainting_f)
             self._fe_key = key
             self._fe_wave = waveform    # keep alive so data_ptr cannot be recycled
@@ -314,8 +327,16 @@ class ClassifierFreeDiffRoll(nn.Module):
             z = torch.randn(B, Tm, 88, device=eng.device)   # reference: torch.randn_like(x), global generator
         eng.step(sampler, xx, z, t_index, w)
         if spec is None:
-            spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)   # generation returns the uncond spec
+            spec = self._uncond_spec(B, Tm)
         return xx.unsqueeze(1), spec
+
+    def _uncond_spec(self, B, Tm):
+        """The spectrogram generation_ddpm_x0 returns (task/diffusion.py:979-997: that of its sampling=True forward):
+        -1 everywhere, or the learned one under condition='trainable_spec' (model/diffwave.py:656-660)."""
+        eng = self.engine
+        if self.hparams.condition == "trainable_spec":
+            return self.trainable_parameters.detach()[:, :Tm].to(eng.device, torch.float32)
+        return torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
 
     def ddpm_x0(self, x, waveform, t_index, noise=None):
         """task/diffusion.py:831-853."""
@@ -374,10 +395,9 @@ class ClassifierFreeDiffRoll(nn.Module):
             Tm = spec.shape[-1]
         else:
             Tm = T if waveform is None else min(T, waveform.shape[-1] // eng.hop_length + 1)
-            spec = torch.full((B, eng.n_mels, Tm), -1.0, device=eng.device)
             if self.hparams.condition == "trainable_spec":
                 Tm = min(T, 641)
-                spec = self.trainable_parameters.detach()[:, :Tm].to(eng.device, torch.float32)
+            spec = self._uncond_spec(B, Tm)
         # a fresh roll buffer per call: the engine's captured chain runs on its own work buffer, so caller
         # addresses never force a re-capture
         xb = x_T.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].clone(memory_format=torch.contiguous_format)
@@ -430,6 +450,8 @@ class ClassifierFreeDiffRoll(nn.Module):
         xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         eng.step(sampler, xx, None, t_index, w, seed, first_sample)
+        if spec is None:
+            spec = self._uncond_spec(B, Tm)
         return xx.unsqueeze(1), spec
 
     def predict_step(self, batch, batch_idx=0):

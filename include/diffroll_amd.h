@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 5
+#define DR_ABI_VERSION 6
 
 enum {
     DR_OK = 0,
@@ -233,6 +233,27 @@ int dr_set_precision(dr_engine* e, int mode);
  * on the launch stream when enabled: returns launches and total milliseconds since last reset. */
 int dr_profile_enable(dr_engine* e, int on);
 int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset);
+/* The same plus the ALGORITHMIC FLOPs of the timed launches (SURVEY.md 8d per-frame figures x the frames each
+ * launch processed) and the name of the timed kernel: the dominant kernel is the fused residual-stack kernel
+ * when the launch geometry allows it (below), else the dilated conv + gate kernel. */
+int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double* total_flops, char* name,
+                       size_t name_len, int reset);
+
+/*
+ * Integer options (defaults in brackets).  Changing one drops a captured chain.
+ *   "fused_stack"      [1] the residual layers of an evaluation (model/diffwave.py:678-681: 15 x ResidualBlock.forward,
+ *                          :134-151) run as ONE persistent launch whenever samples x frame tiles x M tiles fits the
+ *                          chip's CUs in one resident round (the BASELINE configurations 2-4 do); 0 = one launch per
+ *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches).
+ *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
+ *                          0 = one weight panel per XCD.  Performance only.
+ *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
+ */
+int dr_set_option(dr_engine* e, const char* name, int value);
+/* Synchronises the device.  *timed_out != 0: a group barrier of the fused kernel ran into its spin bound (results
+ * of that launch are invalid; never observed in a healthy run) - the counters are reset.  ticks (optional,
+ * n_ticks <= 128): the phase tick marks of the last launch recorded with "stack_ticks". */
+int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* ticks, int n_ticks);
 
 /* Standalone launch of the fused dilated-conv+gate kernel of layer `layer` on the engine's
  * workspace activations (for micro-benchmarks / roofline): returns 0. */

@@ -69,7 +69,9 @@ def test_no_gpu_fails_loudly(lib):
     # python wrapper raises
     from diffroll_amd import ClassifierFreeDiffRoll, EngineError
     m = ClassifierFreeDiffRoll(64, False, "fixed", 229, [0, 1, "imagewise"], residual_layers=2, kernel_size=3,
-                               dilation_base=2, sampling={"type": "cfdg_ddpm_x0", "w": 0.5})
+                               dilation_base=2, sampling={"type": "cfdg_ddpm_x0", "w": 0.5},
+                               spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0,
+                                              f_max=8000, center=True, normalized=True, pad_mode="reflect"))
     with pytest.raises(EngineError):
         m.engine
     with pytest.raises(EngineError):

@@ -81,3 +81,53 @@ def test_sharded_sampling_equals_single_process(B, use_noise):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert torch.equal(full, single)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+def test_sequential_rank_emulation_equals_single_process(G):
+    """sample_sharded_sequential (what the GPU tests use to cover G ranks on one device) walks the same shard /
+    pad / un-pad code as the collective path: with the stand-in model it must reproduce the unsharded result
+    exactly, empty shards included (B = 5 over 8 ranks)."""
+    from diffroll_amd.distributed import pad_shard, sample_sharded, sample_sharded_sequential, shard_bounds, unpad_gathered
+    torch.manual_seed(1)
+    B = 5
+    x = torch.randn(B, 1, 6, 88)
+    wav = torch.randn(B, 64)
+    noise = torch.randn(4, B, 1, 6, 88)
+    for nz in (noise, None):
+        single = sample_sharded(FakeModel(), x, wav, nz, seed=9)
+        assert torch.equal(sample_sharded_sequential(FakeModel(), x, wav, nz, seed=9, world_size=G), single)
+    # the pad / un-pad pair is the identity on any partition
+    parts = [x[slice(*shard_bounds(B, r, G))] for r in range(G)]
+    assert torch.equal(unpad_gathered(torch.cat([pad_shard(p, B, G) for p in parts], 0), B, G), x)
+
+
+def test_bench_gpus_flag_spawns_or_refuses_with_a_device_count_message():
+    """`python bench.py --gpus N` starts its own ranks; with fewer than N GPUs visible (here: none) it must say so -
+    a device-count message, not a hint to wrap the command in a launcher."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_sharding.py")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300, cwd=root)
+    assert r.returncode != 0
+    assert "2 GPUs requested but only 0 HIP device(s) visible" in r.stdout + r.stderr
+
+
+def test_launch_helpers():
+    from diffroll_amd import launch
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        assert not launch.under_launcher() and launch.rank_env() == (0, 1, 0)
+        os.environ.update(RANK="3", WORLD_SIZE="8", LOCAL_RANK="3")
+        assert launch.under_launcher() and launch.rank_env() == (3, 8, 3)
+    finally:
+        for k, v in env_backup.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert launch.dist_info(None)["ranks_seen"] == 1
+    p = launch.free_port()
+    assert 1024 < p < 65536

@@ -2,10 +2,12 @@
 reference and against the CPU oracle.  Needs a real MI355X: ``pytest -m gpu``.
 
 Tolerances (fp32 everywhere; the kernels use the exact-fp32 MFMA, so differences come only from
-summation order, the DFT-vs-FFT front-end and libm differences in exp/tanh/log):
-  * one network evaluation:      atol 5e-5  (outputs are O(1))
-  * one reverse step / chain:    atol 1e-4
-  * normalised log-mel:          atol 2e-4  (values in [0,1])
+summation order, the DFT-vs-FFT front-end and the hardware exp/rcp of the gate):
+  * one network evaluation:      atol 1e-5  (outputs are O(1); observed 2.1e-6 on the full-size net)
+  * one reverse step / chain:    atol 2e-5  (observed 2.5e-6; SURVEY.md 8c proposes 2e-5 per kernel)
+  * normalised log-mel:          atol 1e-4  (values in [0,1]; observed 2.0e-5, DFT-as-GEMM vs torch's FFT)
+  * same clips, other shard / batch geometry (other tile flavour or split-K order): atol 1e-5 (observed ~1e-6)
+i.e. 4-5x the observed margins (tests/parity_margins.py prints them): a 10x kernel regression fails.
 """
 import json
 import os
@@ -18,9 +20,10 @@ from oracle import diffroll_ref as R
 
 pytestmark = pytest.mark.gpu
 
-ATOL_FWD = 5e-5
-ATOL_STEP = 1e-4
-ATOL_SPEC = 2e-4
+ATOL_FWD = 1e-5
+ATOL_STEP = 2e-5
+ATOL_SPEC = 1e-4
+ATOL_SHARD = 1e-5
 
 
 def load(golden_dir, name):
@@ -56,7 +59,14 @@ def fixture_model(g, **kw):
 
 
 def maxdiff(a, b):
-    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    d = float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+    log = os.environ.get("DR_PARITY_LOG")          # observed margins, one line per comparison (tools/gpu_*.sh)
+    if log:
+        import inspect
+        fr = inspect.stack()[1]
+        with open(log, "a") as f:
+            f.write(f"{fr.function}:{fr.lineno} {d:.3e}\n")
+    return d
 
 
 # --------------------------------------------------------------------------------------------
@@ -169,7 +179,7 @@ def test_full_size_forward_vs_oracle(full_model):
 
 def test_config1_chain_vs_oracle():
     """BASELINE config 1: k=9, 50 steps, batch 1, 4 s clip, cfdg w=0.5 - whole chain vs the oracle,
-    and the thresholded roll (> 0.5) identical except within 1e-4 of the threshold."""
+    and the thresholded roll (> 0.5) identical except within the tolerance of the threshold."""
     hp = dict(R.DEFAULT_HP)
     hp["timesteps"] = 50
     p = R.synthetic_params(hp, seed=0)
@@ -186,7 +196,7 @@ def test_config1_chain_vs_oracle():
     roll = roll.cpu()
     d = maxdiff(roll, ref)
     assert d <= ATOL_STEP, d
-    near = (ref - 0.5).abs() < 1e-4
+    near = (ref - 0.5).abs() < ATOL_STEP
     assert bool((((roll > 0.5) == (ref > 0.5)) | near).all())
 
 
@@ -255,10 +265,58 @@ def test_config3_generation_steps_vs_oracle(full_model):
     assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
 
 
+def test_config2_real_batch_guided_step_vs_oracle(full_model):
+    """BASELINE config 2 at its REAL batch: 16 clips of 125 frames through the full k=9 network, one classifier-free
+    guided reverse step (cfdg_ddpm_x0, w=0.5: a 32-sample evaluation, the launch geometry of the bench line) and
+    the conditional evaluation on its own, against the oracle (task/diffusion.py:943-969)."""
+    hp, p, m = full_model
+    torch.manual_seed(16)
+    B, Tn = 16, 125
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(B, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    t = 150
+    with torch.no_grad():
+        spec = R.frontend(wav, hp, Tn)
+        ref = R.reverse_step(p, hp, sch, "cfdg_ddpm_x0", x, spec, t, z, 0.5)
+        ref_c, _ = R.forward(p, hp, x, wav, torch.tensor(t).repeat(B))
+    out, sp = m.reverse_diffusion(x, wav, t, noise=z)
+    assert maxdiff(sp.cpu(), spec) <= ATOL_SPEC
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+    x0_c, _ = m(x, wav, torch.tensor(t).repeat(B))
+    assert maxdiff(x0_c.cpu(), ref_c) <= ATOL_FWD, maxdiff(x0_c.cpu(), ref_c)
+
+
+def test_config4_full_size_inpainting_step_vs_oracle(full_model):
+    """BASELINE config 4 per-GPU geometry at full size: inpainting_ddpm_x0 (w=0.5) on 16 clips of 125 frames with
+    the spectrogram frames [T/4, T/2) masked to -1 after normalisation (model/diffwave.py:649-654; the reference
+    never masks the roll, task/diffusion.py:999-1025) - two consecutive reverse steps against the oracle."""
+    hp, p, _ = full_model
+    B, Tn = 16, 125
+    it = [Tn // 4, Tn // 2]
+    m = make_model(hp, p, sampler="inpainting_ddpm_x0", w=0.5, inpainting_t=it)
+    torch.manual_seed(44)
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(2, B, 1, Tn, 88)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    ref, out = x, x
+    with torch.no_grad():
+        spec = R.frontend(wav, hp, Tn, inpainting_t=it)
+        for i, t in enumerate((199, 198)):
+            ref = R.reverse_step(p, hp, sch, "inpainting_ddpm_x0", ref, spec, t, z[i], 0.5)
+    assert bool((spec[:, :, it[0]:it[1]] == -1).all()) and not bool((spec[:, :, :it[0]] == -1).any())
+    for i, t in enumerate((199, 198)):
+        out, sp = m.reverse_diffusion(out, wav, t, noise=z[i])
+    assert maxdiff(sp.cpu(), spec) <= ATOL_SPEC
+    assert maxdiff(out.cpu(), ref) <= ATOL_STEP, maxdiff(out.cpu(), ref)
+
+
 def test_full_200_step_guided_chain_vs_oracle(full_model):
     """The north_star statement itself at full depth: the k=9, C=512, 15-layer network, all 200 reverse steps of
     cfdg_ddpm_x0 (w=0.5) on 4-s clips with identical injected noise - final roll within the fp32 tolerance of the
-    oracle and the thresholded roll (> 0.5, what frame-F1 is computed from) identical except within 1e-4 of the
+    oracle and the thresholded roll (> 0.5, what frame-F1 is computed from) identical except within the tolerance of the
     threshold; in both precisions."""
     hp, p, _ = full_model
     torch.manual_seed(200)
@@ -268,7 +326,7 @@ def test_full_200_step_guided_chain_vs_oracle(full_model):
     noise = torch.randn(hp["timesteps"], B, 1, Tn, 88)
     with torch.no_grad():
         ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
-    near = (ref - 0.5).abs() < 1e-4
+    near = (ref - 0.5).abs() < ATOL_STEP
     for precision in ("f32", "bf16x3"):
         m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, precision=precision)
         roll, _ = m.sample(x, wav, noise=noise)
@@ -313,11 +371,11 @@ def test_batch_shard_invariance_injected_and_philox(full_model):
     full, _ = m.sample(x, wav, noise=noise)
     lo, _ = m.sample(x[:4], wav[:4], noise=noise[:, :4])
     hi, _ = m.sample(x[4:], wav[4:], noise=noise[:, 4:])
-    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_STEP / 4
+    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_SHARD
     full, _ = m.sample(x, wav, seed=7)
     lo, _ = m.sample(x[:4], wav[:4], seed=7, first_sample=0)
     hi, _ = m.sample(x[4:], wav[4:], seed=7, first_sample=4)
-    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_STEP / 4
+    assert maxdiff(full.cpu(), torch.cat([lo, hi], 0).cpu()) <= ATOL_SHARD
     hi2, _ = m.sample(x[4:], wav[4:], seed=7, first_sample=4)
     assert torch.equal(hi, hi2)                      # same geometry: bitwise reproducible
     other, _ = m.sample(x, wav, seed=8)
@@ -467,7 +525,7 @@ def test_large_batch_self_consistency(full_model):
     assert bool(torch.isfinite(big).all())
     for lo in (0, 40, 92):
         small, _ = m.sample(x[lo:lo + 4], wav[lo:lo + 4], seed=5, first_sample=lo)
-        assert maxdiff(big[lo:lo + 4].cpu(), small.cpu()) <= ATOL_STEP / 4
+        assert maxdiff(big[lo:lo + 4].cpu(), small.cpu()) <= ATOL_SHARD
 
 
 def test_cfg_weight_zero_equals_conditional_sampler(full_model):
@@ -479,7 +537,7 @@ def test_cfg_weight_zero_equals_conditional_sampler(full_model):
     m1 = make_model(hp, p, sampler="ddpm_x0")
     a, _ = m0.sample(x, wav, noise=noise)
     b, _ = m1.sample(x, wav, noise=noise)
-    assert maxdiff(a.cpu(), b.cpu()) <= ATOL_STEP / 4
+    assert maxdiff(a.cpu(), b.cpu()) <= ATOL_SHARD
 
 
 def test_philox_noise_is_standard_normal(full_model):
@@ -752,7 +810,8 @@ def test_random_chains_vs_oracle():
             residual_channels=hp["residual_channels"], unconditional=False, condition=hp["condition"], n_mels=hp["n_mels"],
             norm_args=[0, 1, hp["norm_mode"]], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
             dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
-            spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000),
+            spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000,
+                           normalized=True),
             inpainting_t=it, inpainting_f=i_f, timesteps=hp["timesteps"], training={"mode": "x_0"},
             sampling={"type": sampler, "w": w}, precision="bf16x3" if case % 5 == 4 else "f32")
         m.load_state_dict(p)
@@ -802,7 +861,7 @@ def test_framewise_normalisation_golden(golden_dir):
               norm_args=[0, 1, "framewise"], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
               dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
               spec_args=dict(sample_rate=16000, n_fft=hp["n_fft"], hop_length=hp["hop_length"], n_mels=hp["n_mels"], f_min=0,
-                             f_max=8000), timesteps=hp["timesteps"], training={"mode": "x_0"},
+                             f_max=8000, normalized=True), timesteps=hp["timesteps"], training={"mode": "x_0"},
               sampling={"type": "cfdg_ddpm_x0", "w": 0.5})
     m = ClassifierFreeDiffRoll(**kw)
     m.load_state_dict(p)
@@ -831,7 +890,7 @@ def test_trainable_spec_condition_golden(golden_dir):
             norm_args=[0, 1, "imagewise"], residual_layers=hp["residual_layers"], kernel_size=hp["kernel_size"],
             dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
             spec_args=dict(sample_rate=16000, n_fft=hp["n_fft"], hop_length=hp["hop_length"], n_mels=hp["n_mels"], f_min=0,
-                           f_max=8000), timesteps=hp["timesteps"], training={"mode": "x_0"},
+                           f_max=8000, normalized=True), timesteps=hp["timesteps"], training={"mode": "x_0"},
             sampling={"type": sampler, "w": w})
         m.load_state_dict(p)
         return m
@@ -871,7 +930,8 @@ def test_cosine_beta_schedule_steps_vs_oracle(golden_dir):
     m = ClassifierFreeDiffRoll(
         residual_channels=64, unconditional=False, condition="fixed", n_mels=hp["n_mels"], norm_args=[0, 1, "imagewise"],
         residual_layers=3, kernel_size=9, dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
-        spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000),
+        spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=hp["n_mels"], f_min=0, f_max=8000,
+                           normalized=True),
         timesteps=50, training={"mode": "x_0"}, sampling={"type": "cfdg_ddpm_x0", "w": 0.5}, beta_schedule="cosine")
     m.load_state_dict(p)
     betas = T(np.load(os.path.join(golden_dir, "beta_schedules.npz"))["cosine_50"])

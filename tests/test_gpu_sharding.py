@@ -1,0 +1,145 @@
+"""Row (e) on hardware: the batch-shard path of diffroll_amd.distributed driven by the REAL engine.
+
+Only one GPU is leased for the test run, so the N-rank job is covered from both sides:
+  * the collective side - a 1-rank RCCL process group (backend 'nccl'): init_process_group with device_id,
+    all_gather_into_tensor, all_reduce and barrier execute on the device, through the same sample_sharded /
+    gather_rolls code the N-rank job runs;
+  * the partition side - G in {2, 3, 8} ranks emulated in turn on the one device through sample_shard()'s own
+    slicing (incl. ranks whose shard is empty) and the same pad / un-pad code as the gather: the assembled result
+    must equal the unsharded one (Philox is keyed by the global sample index).
+`python bench.py --gpus 2` on a 1-GPU box must fail with a device-count message, not a launcher hint.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import diffroll_ref as R
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ATOL_SHARD = 1e-5      # other local batch size -> other tile flavour / split-K order: fp32 round-off (observed ~1e-6)
+
+
+def _model(sampler="cfdg_ddpm_x0", layers=4, steps=12, k=9, C=128):
+    from test_gpu_parity import make_model
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=C, residual_layers=layers, kernel_size=k, timesteps=steps)
+    p = R.synthetic_params(hp, seed=11)
+    return hp, p, make_model(hp, p, sampler=sampler, w=0.5)
+
+
+@pytest.mark.parametrize("G", [2, 3, 8])
+@pytest.mark.parametrize("mode", ["philox", "injected"])
+def test_fake_ranks_equal_unsharded(G, mode):
+    """B = 5 clips over G ranks: shards of 3+2, 2+2+1 and 1+1+1+1+1+0+0+0 (three empty ranks)."""
+    from diffroll_amd.distributed import sample_sharded, sample_sharded_sequential, shard_bounds
+    hp, p, m = _model()
+    torch.manual_seed(5)
+    B, Tn = 5, 40
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    noise = torch.randn(hp["timesteps"], B, 1, Tn, 88) if mode == "injected" else None
+    whole = sample_sharded(m, x, wav, noise, seed=3)                 # no process group: world = 1
+    assert whole.shape == (B, 1, Tn, 88) and bool(torch.isfinite(whole).all())
+    parts = sample_sharded_sequential(m, x, wav, noise, seed=3, world_size=G)
+    assert parts.shape == whole.shape
+    d = float((parts - whole).abs().max())
+    assert d <= ATOL_SHARD, d
+    sizes = [shard_bounds(B, r, G) for r in range(G)]
+    assert sum(hi - lo for lo, hi in sizes) == B and (G != 8 or sum(hi == lo for lo, hi in sizes) == 3)
+    if mode == "injected":                                           # and both equal the oracle's chain
+        with torch.no_grad():
+            ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+        assert float((parts.cpu() - ref).abs().max()) <= 2e-5
+
+
+def test_fake_ranks_generation_without_waveform():
+    from diffroll_amd.distributed import sample_sharded, sample_sharded_sequential
+    hp, p, m = _model(sampler="generation_ddpm_x0")
+    torch.manual_seed(6)
+    x = torch.randn(6, 1, 48, 88)
+    whole = sample_sharded(m, x, None, seed=1)
+    parts = sample_sharded_sequential(m, x, None, seed=1, world_size=4)
+    assert float((parts - whole).abs().max()) <= ATOL_SHARD
+
+
+_RANK_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+from diffroll_amd import launch
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist = launch.init_process_group(dev, force_single=True)         # 1-rank RCCL group
+info = launch.dist_info(dist)
+assert info["ranks_seen"] == 1 and info["backend"] == "nccl", info
+from test_gpu_sharding import _model
+from diffroll_amd.distributed import sample_sharded, gather_rolls, world
+assert world() == (0, 1)
+hp, p, m = _model()
+torch.manual_seed(5)
+B, Tn = 3, 40
+wav = 0.1 * torch.randn(B, Tn * 512)
+x = torch.randn(B, 1, Tn, 88)
+a = sample_sharded(m, x, wav, seed=3)                            # through all_gather_into_tensor (1 rank)
+roll, _ = m.sample(x, wav, seed=3)
+assert torch.equal(a, roll), float((a - roll).abs().max())
+g = gather_rolls(roll)
+assert torch.equal(g, roll)
+t = torch.ones(4, device=dev)
+dist.all_reduce(t)
+dist.barrier()
+torch.cuda.synchronize()
+assert float(t.sum()) == 4.0
+dist.destroy_process_group()
+print("RANK_OK " + json.dumps(info))
+"""
+
+
+def test_one_rank_rccl_group_runs_the_collective_path():
+    """init_process_group('nccl', device_id=...) + all_gather_into_tensor + all_reduce + barrier on the device, in a
+    child process (a process group is process-global state)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", _RANK_SCRIPT.format(root=ROOT)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_one_rank_under_torch_distributed_run():
+    """The driver's own launch line with one local rank: python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1 (config 1: the 50-step single clip, seconds) - the JSON line reports the RCCL group."""
+    import json
+    from diffroll_amd.launch import free_port
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "1",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-split", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["dist"]["ranks_seen"] == 1 and j["dist"]["backend"] == "nccl", j["dist"]
+    assert j["value"] > 0 and j["config"]["baseline_config"] == 1
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    n = torch.cuda.device_count()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    msg = r.stdout + r.stderr
+    assert f"only {n} HIP device" in msg and "torch.distributed.run" not in msg.split("only")[0][-200:], msg[-1000:]

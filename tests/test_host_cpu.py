@@ -249,6 +249,65 @@ def test_checkpoint_with_omegaconf_shaped_hparams_loads_without_omegaconf(tmp_pa
         assert torch.equal(m2.state_dict()[k], v)
 
 
+def test_checkpoint_interpolations_resolve_against_the_root(tmp_path):
+    """Real reference checkpoints carry spec_args = cfg.spec.args with `sample_rate: ${sampling_rate}` and
+    `hop_length: ${hop_length}` (config/spec/mel.yaml, train_spec_roll.py:30): the pickled value nodes hold those
+    STRINGS and a `_parent` chain up to the Hydra root.  The reader resolves them without omegaconf."""
+    import sys, types
+    fake = types.ModuleType("omegaconf_fake_interp")
+
+    class DictConfig:
+        def __init__(self, content, parent=None):
+            self._parent = parent
+            self._content = {k: wrap(v, self) for k, v in content.items()}
+
+    class AnyNode:
+        def __init__(self, v, parent):
+            self._val = v
+            self._parent = parent
+
+    def wrap(v, parent):
+        return DictConfig(v, parent) if isinstance(v, dict) else AnyNode(v, parent)
+
+    for cls_ in (DictConfig, AnyNode):
+        cls_.__module__ = fake.__name__
+        cls_.__qualname__ = cls_.__name__
+        setattr(fake, cls_.__name__, cls_)
+    sys.modules[fake.__name__] = fake
+    root = DictConfig(dict(sampling_rate=16000, hop_length=512, tag="k${model.args.kernel_size}_sr${sampling_rate}",
+                           model=dict(args=dict(kernel_size=9)),
+                           spec=dict(args=dict(sample_rate="${sampling_rate}", n_fft=2048, hop_length="${hop_length}",
+                                               n_mels=229, f_min=0, f_max=8000, center=True, normalized=True,
+                                               pad_mode="reflect", alias="${.n_fft}", up="${..other}",
+                                               stamp="${now:%Y}", missing="${nope.nothing}"),
+                                     other=7)))
+    spec_args = root._content["spec"]._content["args"]
+    m = make(kernel_size=9)
+    hp = dict(residual_channels=32, unconditional=False, condition="fixed", n_mels=229, norm_args=[0, 1, "imagewise"],
+              residual_layers=3, kernel_size=9, dilation_base=2, dilation_bound=4, spec_dropout=0.1, timesteps=8,
+              spec_args=spec_args, sampling=dict(type="cfdg_ddpm_x0", w=0), training=dict(mode="x_0"))
+    path = str(tmp_path / "interp.ckpt")
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": hp}, path)
+    del sys.modules[fake.__name__]
+    from diffroll_amd.checkpoint import load_checkpoint, to_plain
+    sa = load_checkpoint(path)["hyper_parameters"]["spec_args"]
+    assert sa["sample_rate"] == 16000 and sa["hop_length"] == 512          # root-relative, type preserved
+    assert sa["alias"] == 2048 and sa["up"] == 7                            # relative to the node's container(s)
+    assert sa["stamp"] == "${now:%Y}" and sa["missing"] == "${nope.nothing}"   # left as they are, never guessed
+    ck = torch.load(path, weights_only=False, pickle_module=__import__("diffroll_amd.checkpoint", fromlist=["x"])._TolerantPickle)
+    rt = ck["hyper_parameters"]["spec_args"]
+    from diffroll_amd.checkpoint import _root_of
+    assert to_plain(_root_of(rt))["tag"] == "k9_sr16000"                   # string interpolation
+    # and the facade builds from it (the alias / stamp keys are not MelSpectrogram arguments: drop them first)
+    from diffroll_amd import ClassifierFreeDiffRoll
+    from diffroll_amd.checkpoint import constructor_kwargs
+    kw = constructor_kwargs(ClassifierFreeDiffRoll, load_checkpoint(path)["hyper_parameters"], {})
+    for extra in ("alias", "up", "stamp", "missing"):
+        kw["spec_args"].pop(extra)
+    m2 = ClassifierFreeDiffRoll(**kw)
+    assert m2._engine_kwargs["sample_rate"] == 16000 and m2._engine_kwargs["hop_length"] == 512
+
+
 def test_note_metrics_against_exhaustive_matching():
     """diffroll_amd.metrics (onset-only note matching of mir_eval's precision_recall_f1_overlap, restated:
     mir_eval is absent) against an exhaustive maximum-matching search on small random cases, plus known answers."""
@@ -331,6 +390,14 @@ def test_facade_rejects_unsupported_front_end_options():
             make(bad)
     with pytest.raises(TypeError):
         make({"not_an_argument": 1})
+    # torchaudio's default for `normalized` is False: a spec_args without the key is a different front-end in the
+    # reference, so it is rejected rather than silently normalised
+    sa = dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000)
+    with pytest.raises(NotImplementedError):
+        ClassifierFreeDiffRoll(residual_channels=64, unconditional=False, condition="fixed", n_mels=229,
+                               norm_args=[0, 1, "imagewise"], residual_layers=2, kernel_size=3, spec_args=sa)
+    with pytest.raises(NotImplementedError):
+        make({"normalized": False})
     with pytest.raises(ValueError):
         make({"n_mels": 128})
     with pytest.raises(ValueError):

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Fused residual-stack kernel vs one launch per phase: bitwise comparison of a guided step / generation step at
+BASELINE config 2 / 3 geometry, then chain timing of both (and both block mappings), plus the in-kernel phase
+tick marks.    python tools/stack_check.py [--quick]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--config", type=int, default=2)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS[args.config]
+    hp = dict(bench.HP)
+    hp.update(kernel_size=cfg["k"], timesteps=cfg["S"])
+    T = cfg["L"] // 512
+    m = bench.build_model(dev, hp=hp, sampler=cfg["sampler"])
+    eng = m.engine
+    g = torch.Generator().manual_seed(5)
+    B = cfg["B"]
+    wav = (0.1 * torch.randn(B, cfg["L"], generator=g)).to(dev)
+    x = torch.randn(B, 1, T, 88, generator=g).to(dev)
+    z = torch.randn(B, 1, T, 88, generator=g).to(dev)
+
+    def step(t=150):
+        out, _ = m.reverse_diffusion(x, wav, t, noise=z)
+        return out
+
+    eng.set_option("fused_stack", 0)
+    ref = step()
+    torch.cuda.synchronize()
+    for xcd in (1, 0):
+        eng.set_option("fused_stack", 1)
+        eng.set_option("fused_stack_xcd", xcd)
+        for rep in range(3):
+            out = step()
+            flag, _ = eng.stack_status()
+            same = bool(torch.equal(out, ref))
+            d = float((out - ref).abs().max())
+            print(f"fused (xcd mapping {xcd}) rep {rep}: timed_out={flag} bitwise_equal={same} max|diff|={d:.3e}", flush=True)
+            if flag or not same:
+                bad = (out != ref).nonzero()
+                print("  first mismatches:", bad[:5].tolist(), "count", len(bad))
+                if flag:
+                    return 1
+    if args.quick:
+        return 0
+    # the same body tick marks from the per-phase launches, inside a real step (weights cold, as in the chain)
+    eng.set_option("fused_stack", 0)
+    eng.set_option("stack_ticks", 1)
+    step()
+    flag, ticks = eng.stack_status(128)
+    print(f"unfused: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, "
+          f"first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
+    eng.set_option("stack_ticks", 0)
+    eng.set_option("fused_stack", 1)
+    # phase ticks (shader-clock cycles of block 0, barrier waits included)
+    for xcd in (1, 0):
+        eng.set_option("fused_stack_xcd", xcd)
+        eng.set_option("stack_ticks", 1)
+        step()
+        flag, ticks = eng.stack_status(128)
+        print(f"xcd={xcd}: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
+        ticks = ticks[:2 * hp["residual_layers"] + 2]
+        nz = [t for t in ticks[:-1] if t]
+        if len(nz) > 1:
+            d = [b - a for a, b in zip(nz[:-1], nz[1:])]
+            conv = [v for i, v in enumerate(d) if (len(d) - i) % 2 == 0]
+            pw = [v for i, v in enumerate(d) if (len(d) - i) % 2 == 1]
+            print(f"xcd={xcd}: phase ticks: conv mean {sum(conv) / max(len(conv), 1):.0f}, 1x1 mean {sum(pw) / max(len(pw), 1):.0f}, "
+                  f"total {nz[-1] - nz[0]}; per phase {d}", flush=True)
+        eng.set_option("stack_ticks", 0)
+
+    def chain_ms(n=2):
+        m._fe_key = None
+        m.sample(x, wav, seed=0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m._fe_key = None
+            r, _ = m.sample(x, wav, seed=0)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n, r
+
+    eng.set_option("fused_stack", 0)
+    t_un, r_un = chain_ms()
+    for xcd in (1, 0):
+        eng.set_option("fused_stack", 1)
+        eng.set_option("fused_stack_xcd", xcd)
+        t_f, r_f = chain_ms()
+        flag, _ = eng.stack_status()
+        print(f"chain: unfused {t_un:.1f} ms, fused(xcd={xcd}) {t_f:.1f} ms ({100 * (t_un - t_f) / t_un:+.2f} %), "
+              f"bitwise equal rolls: {bool(torch.equal(r_un, r_f))}, timed_out={flag}", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
