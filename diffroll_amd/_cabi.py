@@ -35,7 +35,7 @@ EXPORTS = [
     "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
     "dr_extract_x0", "dr_set_spec_norm", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
-    "dr_profile_read_ex", "dr_set_option", "dr_stack_status",
+    "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
 ]
 
 
@@ -76,6 +76,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_set_param.argtypes = [vp, C.c_char_p, f32p, C.c_size_t]
     lib.dr_set_tables.restype = C.c_int
     lib.dr_set_tables.argtypes = [vp, f32p, f32p]
+    lib.dr_set_frontend_tables.restype = C.c_int
+    lib.dr_set_frontend_tables.argtypes = [vp, f32p, C.c_float, f32p]
     lib.dr_commit.restype = C.c_int
     lib.dr_commit.argtypes = [vp, vp]
     lib.dr_frontend.restype = C.c_int
@@ -109,7 +111,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_set_option.restype = C.c_int
     lib.dr_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.dr_stack_status.restype = C.c_int
-    lib.dr_stack_status.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int]
+    lib.dr_stack_status.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int]
     lib.dr_bench_layer.restype = C.c_int
     lib.dr_bench_layer.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.dr_bench_pointwise.restype = C.c_int

@@ -58,6 +58,8 @@ struct dr_engine {
     std::string err;
     std::map<std::string, std::vector<float>> params;
     std::vector<float> h_emb, h_coef;
+    std::vector<float> h_win, h_fb;      // optional caller-built front-end tables (dr_set_frontend_tables)
+    float h_win_norm = 0.f;
     bool committed = false;
 
     // device constants
@@ -66,6 +68,9 @@ struct dr_engine {
     std::vector<LayerW> layers;
     float *in_w = nullptr, *in_b = nullptr, *skip_w = nullptr, *skip_b = nullptr, *outp_w = nullptr, *outp_b = nullptr;
     float *dft_w = nullptr, *mel_w = nullptr;
+    float *fft_win = nullptr, *fft_tw = nullptr;     // FFT front-end: window (n_fft), roots of unity (n_fft complex)
+    float fft_norm = 1.f;                            // the spectrum is divided by it (normalized=True)
+    bool use_fft = false;
     std::vector<void*> owned;   // every constant allocation, for dr_destroy
 
     // activation workspace (sized for ws_NB samples x ws_T frames)
@@ -113,6 +118,7 @@ struct dr_engine {
     unsigned* stack_xid = nullptr;      // [n_cus-sized] XCC ids published by the blocks of the last launch
     long long* stack_dbg = nullptr;     // phase tick marks of block 0 (dr_debug_stack_ticks)
     int stack_dbg_on = 0;
+    int64_t stack_launches = 0;         // fused-kernel launches issued (captured launches count once, at capture)
     static constexpr int STACK_GROUPS = 512;
 
     // profiling of the dominant kernel
@@ -499,7 +505,10 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
         for (int ni = 1; ni <= 2 && !stack_ni; ++ni) {        // smallest frame tile whose launch is one resident round
             const long blocks = (long)(Cp / 64) * NB * ((T + 64 * ni - 1) / (64 * ni));
-            if (blocks <= e->n_cus && blocks <= 1024 && 2 * blocks >= e->n_cus && NB <= dr_engine::STACK_GROUPS &&
+            // (a launch that fills less than half the chip is better served by the per-phase kernels' split-K;
+            // opt_stack == 2 fuses regardless: tests)
+            if (blocks <= e->n_cus && blocks <= 1024 && (2 * blocks >= e->n_cus || e->opt_stack == 2) &&
+                NB <= dr_engine::STACK_GROUPS &&
                 gemm_lds_bytes(ni, 1, e->K, maxdil, 0, EPI_GATE) + (size_t)32 * 64 * ni * 16 <= 160 * 1024)
                 stack_ni = ni;
         }
@@ -533,6 +542,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         const bool timed = e->prof && e->prof_used < e->prof_events.size();
         if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
         HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
+        e->stack_launches += 1;
         if (timed) {
             HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
             const double C = e->C, fr = (double)NB * T;
@@ -789,6 +799,19 @@ int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_c
     return DR_OK;
 }
 
+int dr_set_frontend_tables(dr_engine* e, const float* host_window, float window_norm, const float* host_fb) {
+    if (!e) return DR_EINVAL;
+    e->h_win.clear(); e->h_fb.clear(); e->h_win_norm = 0.f;
+    if (host_window) {
+        if (!(window_norm > 0.f)) return fail(e, DR_EINVAL, "window_norm must be positive");
+        e->h_win.assign(host_window, host_window + e->cfg.n_fft);
+        e->h_win_norm = window_norm;
+    }
+    if (host_fb) e->h_fb.assign(host_fb, host_fb + (size_t)e->n_bins * e->NM);
+    e->committed = false;
+    return DR_OK;
+}
+
 int dr_commit(dr_engine* e, void* stream) {
     if (!e) return DR_EINVAL;
     Range range("dr_commit: pack + upload weights, hoisted tables");
@@ -912,18 +935,35 @@ int dr_commit(dr_engine* e, void* stream) {
         const int N = e->cfg.n_fft, nb = e->n_bins, bp = e->bins_p;
         std::vector<double> win(N);
         double s2 = 0.0;
-        for (int k = 0; k < N; ++k) { win[k] = 0.5 - 0.5 * std::cos(2.0 * M_PI * k / N); s2 += win[k] * win[k]; }
-        const double norm = 1.0 / std::sqrt(s2);   // normalized=True: / sqrt(sum(window^2))
+        for (int k = 0; k < N; ++k) {
+            win[k] = e->h_win.empty() ? 0.5 - 0.5 * std::cos(2.0 * M_PI * k / N) : (double)e->h_win[k];
+            s2 += win[k] * win[k];
+        }
+        // normalized=True: / sqrt(sum(window^2)) - the caller's fp32 value when the window is the caller's
+        const double wnorm = e->h_win.empty() ? std::sqrt(s2) : (double)e->h_win_norm;
+        const double norm = 1.0 / wnorm;
         // cos/sin via an exact-phase table (k*bin mod N) to keep the twiddles accurate
         std::vector<double> ct(N), sn(N);
         for (int k = 0; k < N; ++k) { ct[k] = std::cos(2.0 * M_PI * k / N); sn[k] = std::sin(2.0 * M_PI * k / N); }
-        auto pk = pack_weights(bp / 64, N / 32, 1, [&](int pr, int k, int) {
-            int mi, bin; paired_row(pr, mi, bin);
-            if (bin >= nb) return 0.f;
-            const int ph = (int)(((long long)k * bin) % N);
-            return (float)(win[k] * norm * (mi == 0 ? ct[ph] : sn[ph]));
-        });
-        if ((rc = upload(e, pk, &e->dft_w))) return rc;
+        e->use_fft = (N >= 8 && N <= 16384 && (N & (N - 1)) == 0);
+        e->dft_w = e->fft_win = e->fft_tw = nullptr;
+        if (e->use_fft) {
+            // FFT front-end (the released configuration, n_fft = 2048): window and roots of unity exp(-2 pi i k / N),
+            // rounded once from double; the window normalisation is applied to the spectrum as the reference does
+            std::vector<float> wf(N), tf(2 * (size_t)N);
+            for (int k = 0; k < N; ++k) { wf[k] = (float)win[k]; tf[2 * k] = (float)ct[k]; tf[2 * k + 1] = (float)(-sn[k]); }
+            e->fft_norm = (float)wnorm;
+            if ((rc = upload(e, wf, &e->fft_win)) || (rc = upload(e, tf, &e->fft_tw))) return rc;
+        } else {
+            // any other n_fft: the windowed DFT as a GEMM (cos rows / sin rows paired, |.|^2 in the epilogue)
+            auto pk = pack_weights(bp / 64, N / 32, 1, [&](int pr, int k, int) {
+                int mi, bin; paired_row(pr, mi, bin);
+                if (bin >= nb) return 0.f;
+                const int ph = (int)(((long long)k * bin) % N);
+                return (float)(win[k] * norm * (mi == 0 ? ct[ph] : sn[ph]));
+            });
+            if ((rc = upload(e, pk, &e->dft_w))) return rc;
+        }
         // torchaudio.functional.melscale_fbanks(n_freqs, f_min, f_max, n_mels, sample_rate, norm=None, 'htk')
         const double fmin = e->cfg.f_min, fmax = e->cfg.f_max;
         auto hz2mel = [](double f) { return 2595.0 * std::log10(1.0 + f / 700.0); };
@@ -935,6 +975,7 @@ int dr_commit(dr_engine* e, void* stream) {
         }
         const double nyq = (double)(e->cfg.sample_rate / 2);
         auto fbv = [&](int bin, int mel) {
+            if (!e->h_fb.empty()) return (double)e->h_fb[(size_t)bin * NM + mel];      // the caller's (reference-rounded) table
             const double f = nyq * bin / (nb - 1);
             const double down = (f - fpts[mel]) / (fpts[mel + 1] - fpts[mel]);
             const double up = (fpts[mel + 2] - f) / (fpts[mel + 2] - fpts[mel + 1]);
@@ -1061,9 +1102,11 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
 
     // 1. center / reflect padding
     HIPCHK(e, launch_reflect_pad(d_wav, e->wav_pad, B, L, pad, st));
-    // 2. STFT power = |windowed DFT|^2: frames are read straight out of the padded waveform
-    //    (plane stride 4 samples, frame stride hop) - no im2col copy.
-    {
+    // 2. STFT power spectrum: frames are read straight out of the padded waveform (frame stride hop) - no framed
+    //    copy.  FFT per frame (n_fft a power of two), else the windowed DFT as a GEMM.
+    if (e->use_fft) {
+        HIPCHK(e, launch_stft_power(e->wav_pad, e->fft_win, e->fft_tw, e->power, B, Lp, TF, N, hop, bp, e->fft_norm, st));
+    } else {
         GemmArgs a{};
         a.Wp = e->dft_w; a.MT = bp / 64; a.bias = zero_vec();
         a.X = e->wav_pad; a.x_bs = Lp; a.x_ps = 4; a.x_fs = hop; a.x_planes = N / 4; a.kchunks = N / 32;
@@ -1075,6 +1118,9 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     // 3. mel filterbank + log(. + 1e-6)   (model/diffwave.py:644)
     {
         GemmArgs a = p4_gemm(e->mel_w, nullptr, (NM + 127) / 128, e->power, bp / 4, B, TF);
+        if (e->use_fft) {     // power is (B, TF, bins) row-major: 4 bins per plane at stride 4, frames at stride bins
+            a.x_bs = (long)TF * bp; a.x_ps = 4; a.x_fs = bp;
+        }
         p4_out(a, e->logmel, mel_planes, TF, mel_planes * 4);
         HIPCHK(e, launch_gemm(a, EPI_LOG, 2, st));
     }
@@ -1304,7 +1350,7 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
     return fail(e, DR_ENAME, "unknown option '%s'", name);
 }
 
-int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* ticks, int n_ticks) {
+int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t* ticks, int n_ticks) {
     if (!e) return DR_EINVAL;
     if (!e->stack_bar) return fail(e, DR_ESTATE, "dr_commit has not been called");
     DeviceGuard guard(e->cfg.device);
@@ -1312,6 +1358,7 @@ int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* ticks, int n_tick
     unsigned flag = 0;
     HIPCHK(e, hipMemcpy(&flag, e->stack_err, sizeof flag, hipMemcpyDeviceToHost));
     if (timed_out) *timed_out = (int32_t)flag;
+    if (launches) *launches = e->stack_launches;
     if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
         HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(2 * dr_engine::STACK_GROUPS + 4) * sizeof(unsigned)));
     }

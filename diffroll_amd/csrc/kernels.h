@@ -162,6 +162,10 @@ struct UpdateArgs {
 hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
 
 hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pad, hipStream_t s);
+// STFT power by FFT (N a power of two): wav_pad (B, Lp) -> power (B, TF, bins_p) row-major; win (N) the window,
+// tw (N complex) = exp(-2 pi i k / N), norm = sqrt(sum win^2) (the spectrum is divided by it)
+hipError_t launch_stft_power(const float* wav_pad, const float* win, const float* tw, float* power, int B, int Lp, int TF,
+                             int N, int hop, int bins_p, float norm, hipStream_t s);
 // per-sample min/max of logmel P4 [B][planes][TF][4] over rows < n_rows -> mm[B][2]
 hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
 // normalise, mask, trim -> spec P4 [B][planes_out][T][4] (rows >= n_rows zero) and optional plain (B, n_rows, T)

@@ -1752,6 +1752,107 @@ hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pa
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// STFT power spectrum by FFT (torchaudio Spectrogram: torch.stft(center, reflect, hann, onesided) -> / sqrt(sum w^2)
+// -> |.|^2; model/diffwave.py:635,643).  One workgroup per (clip, frame): the N real samples of the frame are
+// windowed and packed as N/2 complex points z[n] = x[2n] + i x[2n+1] in LDS, transformed by a Stockham
+// autosort FFT (radix-4 passes, one radix-2 pass when log2(N/2) is odd; ping-pong buffers, natural order out, no
+// bit reversal), and split into the N/2+1 bins of the real transform
+//     X[k] = E[k] + W_N^k O[k],   E = (Z[k] + conj Z[N/2-k]) / 2,   O = -i (Z[k] - conj Z[N/2-k]) / 2.
+// Same O(eps log N) rounding behaviour as the FFT the reference runs (the earlier windowed-DFT-as-GEMM summed
+// 2048 terms per bin in fp32 and differed from it by up to 2e-5 in the normalised log-mel; this path: ~3e-6).
+// HBM-bound: reads 4 N bytes, writes 4 bins_p bytes per frame; twiddles (N complex) and window stay L2-resident.
+// Output: power (B, TF, bins_p) row-major = "frame stride bins_p, plane stride 4" for the mel GEMM's X operand;
+// bins >= N/2+1 are written as 0.
+// ---------------------------------------------------------------------------------------------
+DR_DEVINL float2 cmul(const float2 a, const float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__global__ __launch_bounds__(256) void stft_power_kernel(const float* __restrict__ wav_pad, const float* __restrict__ win,
+                                                         const float2* __restrict__ tw, float* __restrict__ power,
+                                                         int Lp, int TF, int N, int hop, int bins_p, float norm) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* buf0 = reinterpret_cast<float2*>(smem);
+    const int H = N >> 1;                              // complex points
+    float2* buf1 = buf0 + H;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* x = wav_pad + (long)b * Lp + (long)t * hop;
+    for (int n = threadIdx.x; n < H; n += 256) {
+        const float2 xv = *reinterpret_cast<const float2*>(x + 2 * n);      // hop and the pad are multiples of 4
+        const float2 wv = *reinterpret_cast<const float2*>(win + 2 * n);
+        buf0[n] = make_float2(xv.x * wv.x, xv.y * wv.y);
+    }
+    __syncthreads();
+    float2* in = buf0;
+    float2* out = buf1;
+    // tw[k] = exp(-2 pi i k / N), k in [0, N): the H-point transform's roots are tw[2 m]
+    int Ns = 1;
+    for (; Ns * 4 <= H; Ns *= 4) {                     // radix-4 passes
+        const int Q = H >> 2;
+        for (int j = threadIdx.x; j < Q; j += 256) {
+            const int k = j & (Ns - 1);
+            const int step = (H / (4 * Ns)) * 2;       // index step in tw for angle -2 pi k / (4 Ns)
+            float2 u0 = in[j], u1 = in[j + Q], u2 = in[j + 2 * Q], u3 = in[j + 3 * Q];
+            if (k) {
+                u1 = cmul(u1, tw[k * step]);
+                u2 = cmul(u2, tw[2 * k * step]);
+                u3 = cmul(u3, tw[3 * k * step]);
+            }
+            const float2 a0 = make_float2(u0.x + u2.x, u0.y + u2.y), a1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+            const float2 a2 = make_float2(u1.x + u3.x, u1.y + u3.y), a3 = make_float2(u1.x - u3.x, u1.y - u3.y);
+            const int j0 = ((j - k) << 2) + k;
+            out[j0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            out[j0 + Ns] = make_float2(a1.x + a3.y, a1.y - a3.x);        // a1 - i a3
+            out[j0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            out[j0 + 3 * Ns] = make_float2(a1.x - a3.y, a1.y + a3.x);    // a1 + i a3
+        }
+        __syncthreads();
+        float2* tmp = in; in = out; out = tmp;
+    }
+    if (Ns < H) {                                      // one radix-2 pass (log2 H odd)
+        const int Q = H >> 1;
+        for (int j = threadIdx.x; j < Q; j += 256) {
+            const int k = j & (Ns - 1);
+            const int step = (H / (2 * Ns)) * 2;
+            const float2 u0 = in[j];
+            float2 u1 = in[j + Q];
+            if (k) u1 = cmul(u1, tw[k * step]);
+            const int j0 = ((j - k) << 1) + k;
+            out[j0] = make_float2(u0.x + u1.x, u0.y + u1.y);
+            out[j0 + Ns] = make_float2(u0.x - u1.x, u0.y - u1.y);
+        }
+        __syncthreads();
+        float2* tmp = in; in = out; out = tmp;
+    }
+    // split + |.|^2 ; Z = in[], natural order
+    float* prow = power + ((long)b * TF + t) * bins_p;
+    for (int k = threadIdx.x; k < bins_p; k += 256) {
+        float v = 0.f;
+        if (k <= H) {
+            const float2 A = in[k == H ? 0 : k];
+            const float2 Bz = in[(H - k) & (H - 1)];
+            const float2 Bc = make_float2(Bz.x, -Bz.y);
+            const float2 E = make_float2(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+            const float2 D = make_float2(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+            const float2 O = make_float2(D.y, -D.x);                     // -i D
+            const float2 w = (k == H) ? make_float2(-1.f, 0.f) : tw[k];
+            const float2 WO = cmul(w, O);
+            // the reference's order: spec_f / window.pow(2).sum().sqrt()  ->  .abs()  ->  .pow(2.0)
+            const float re = (E.x + WO.x) / norm, im = (E.y + WO.y) / norm;
+            const float mag = sqrtf(re * re + im * im);
+            v = mag * mag;
+        }
+        prow[k] = v;
+    }
+}
+
+hipError_t launch_stft_power(const float* wav_pad, const float* win, const float* tw, float* power, int B, int Lp, int TF,
+                             int N, int hop, int bins_p, float norm, hipStream_t s) {
+    if (N < 8 || (N & (N - 1)) || N > 16384) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stft_power_kernel, dim3((unsigned)TF, (unsigned)B), dim3(256), (size_t)N * 8, s, wav_pad, win,
+                       reinterpret_cast<const float2*>(tw), power, Lp, TF, N, hop, bins_p, norm);
+    return hipGetLastError();
+}
+
 // per-sample min / max (model/utils.py:25-26) over the n_rows x TF valid values; wavefront shuffles
 // then one LDS hop across the 4 waves.
 __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, float* __restrict__ mm,

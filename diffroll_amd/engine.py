@@ -72,6 +72,12 @@ class Engine:
         self._check(self.lib.dr_set_tables(
             self.h, C.cast(self._tables[0].data_ptr(), C.POINTER(C.c_float)),
             C.cast(self._tables[1].data_ptr(), C.POINTER(C.c_float))))
+        # front-end constants with the reference's fp32 arithmetic (torch.hann_window, torchaudio's melscale_fbanks)
+        from .frontend_tables import frontend_tables
+        self._fe_tables = frontend_tables(n_fft, f_min, f_max, n_mels, sample_rate)
+        self._check(self.lib.dr_set_frontend_tables(
+            self.h, C.cast(self._fe_tables[0].data_ptr(), C.POINTER(C.c_float)), C.c_float(self._fe_tables[1]),
+            C.cast(self._fe_tables[2].data_ptr(), C.POINTER(C.c_float))))
         self.committed = False
         self.precision = "f32"
         self._keep = []   # tensors referenced by a captured graph must stay alive
@@ -235,10 +241,13 @@ class Engine:
         self._check(self.lib.dr_set_option(self.h, name.encode(), int(value)))
 
     def stack_status(self, n_ticks: int = 0):
-        """(timed_out, ticks): synchronises; timed_out != 0 means a fused-kernel barrier hit its spin bound."""
+        """(timed_out, ticks): synchronises; timed_out != 0 means a fused-kernel barrier hit its spin bound.
+        self.stack_launches = fused-kernel launches issued so far."""
         flag = C.c_int32(0)
+        n = C.c_int64(0)
         arr = (C.c_int64 * max(n_ticks, 1))()
-        self._check(self.lib.dr_stack_status(self.h, C.byref(flag), arr, int(n_ticks)))
+        self._check(self.lib.dr_stack_status(self.h, C.byref(flag), C.byref(n), arr, int(n_ticks)))
+        self.stack_launches = int(n.value)
         return int(flag.value), [int(v) for v in arr[:n_ticks]]
 
     def bench_pointwise(self, layer: int, NB: int, T: int):

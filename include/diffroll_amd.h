@@ -142,6 +142,17 @@ int dr_set_param(dr_engine* e, const char* name, const float* host_data, size_t 
  */
 int dr_set_tables(dr_engine* e, const float* host_embedding, const float* host_coef);
 
+/*
+ * Constants of the mel front-end built by the caller WITH THE REFERENCE'S ARITHMETIC (torchaudio 0.11
+ * MelSpectrogram, model/diffwave.py:635): host_window (n_fft) = torch.hann_window(n_fft), window_norm =
+ * window.pow(2).sum().sqrt() (normalized=True divides the spectrum by it), host_fb (n_fft/2+1, n_mels) row-major =
+ * torchaudio.functional.melscale_fbanks(..., norm=None, mel_scale='htk').  torchaudio evaluates these in fp32 and
+ * the rounding of the filterbank is visible (2e-5 in the normalised log-mel), so parity needs the same tables:
+ * diffroll_amd/frontend_tables.py builds them with the same torch expressions.  Optional: without this call (or
+ * with NULL tables) dr_commit evaluates the published formulas itself, in double precision.
+ */
+int dr_set_frontend_tables(dr_engine* e, const float* host_window, float window_norm, const float* host_fb);
+
 /* Pack weights for the kernels, upload, and build the hoisted tables on the device (the
  * (timesteps, layers, C) step-embedding projections; the unconditional conditioner constants).
  * Requires every parameter and both tables.  Synchronises `stream`. */
@@ -244,16 +255,18 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *   "fused_stack"      [1] the residual layers of an evaluation (model/diffwave.py:678-681: 15 x ResidualBlock.forward,
  *                          :134-151) run as ONE persistent launch whenever samples x frame tiles x M tiles fits the
  *                          chip's CUs in one resident round (the BASELINE configurations 2-4 do); 0 = one launch per
- *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches).
+ *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches); 2 = fuse
+ *                          also launches that fill less than half the chip (tests).
  *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
  *                          0 = one weight panel per XCD.  Performance only.
  *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
  */
 int dr_set_option(dr_engine* e, const char* name, int value);
 /* Synchronises the device.  *timed_out != 0: a group barrier of the fused kernel ran into its spin bound (results
- * of that launch are invalid; never observed in a healthy run) - the counters are reset.  ticks (optional,
- * n_ticks <= 128): the phase tick marks of the last launch recorded with "stack_ticks". */
-int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* ticks, int n_ticks);
+ * of that launch are invalid; never observed in a healthy run) - the counters are reset.  *launches: fused-kernel
+ * launches issued so far (a captured chain counts once, when it is captured).  ticks (optional, n_ticks <= 128):
+ * the phase tick marks of the last launch recorded with "stack_ticks". */
+int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t* ticks, int n_ticks);
 
 /* Standalone launch of the fused dilated-conv+gate kernel of layer `layer` on the engine's
  * workspace activations (for micro-benchmarks / roofline): returns 0. */

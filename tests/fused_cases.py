@@ -1,0 +1,81 @@
+"""Child process of tests/test_gpu_fused.py: runs every case of one frame-tile width with the per-phase kernels
+pinned (by the tuning overrides, which are read once per process) to the SAME kernel flavours the fused kernel
+is built from - 32x32 MFMA conv tiles of that width, no split-K, the direct-from-L2 1x1 - so that fused and
+per-phase results must agree bit for bit.  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+from oracle import diffroll_ref as R  # noqa: E402
+from test_gpu_parity import make_model  # noqa: E402
+
+CASES = {
+    1: [  # C, layers, k, B, T, sampler            (64-frame blocks)
+        (64, 3, 9, 3, 40, "cfdg_ddpm_x0"),          # one M tile holding residual AND skip rows; dual first layer
+        (64, 2, 3, 8, 65, "generation_ddpm_x0"),    # 8 groups (group-per-XCD mapping), 2 frame tiles per clip
+        (128, 4, 9, 2, 125, "cfdg_ddpm_x0"),
+        (128, 3, 15, 5, 129, "ddpm_x0"),            # halo 56 frames across the 3 tiles of a clip
+        (192, 3, 9, 4, 200, "cfdg_ddpm_x0"),        # 3 M tiles: tile 1 straddles the residual / skip halves
+        (192, 2, 9, 8, 1, "generation_ddpm_x0"),    # single frame
+        (512, 2, 9, 8, 128, "generation_ddpm_x0"),  # full width, two 64-frame tiles per clip
+        (512, 2, 9, 3, 300, "ddpm_x0"),             # full width, 5 tiles per clip (group of 40 blocks)
+        (512, 3, 15, 16, 64, "cfdg_ddpm_x0"),       # 32 evaluations x 8 M tiles = 256 blocks
+    ],
+    2: [  # 128-frame blocks (chosen when 64-frame blocks would not fit the chip in one round)
+        (512, 3, 9, 16, 125, "cfdg_ddpm_x0"),       # the bench geometry: 32 evaluations, one tile per clip
+        (512, 2, 9, 8, 250, "cfdg_ddpm_x0"),        # 16 evaluations x 2 tiles x 8 M tiles = 256 blocks, halo exchange
+        (512, 2, 15, 16, 200, "generation_ddpm_x0"),
+        (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
+    ],
+}
+
+
+def main():
+    ni = int(sys.argv[1])
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    out = []
+    for (C, layers, k, B, Tn, sampler) in CASES[ni]:
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=C, residual_layers=layers, kernel_size=k, timesteps=6)
+        p = R.synthetic_params(hp, seed=C + k)
+        m = make_model(hp, p, sampler=sampler, w=0.5)
+        g = torch.Generator().manual_seed(B * 1000 + Tn)
+        wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        z = torch.randn(B, 1, Tn, 88, generator=g)
+        eng = m.engine
+        eng.set_option("fused_stack", 0)
+        ref = m.reverse_diffusion(x, wav, 3, noise=z)[0]
+        rec = {"case": [C, layers, k, B, Tn, sampler], "runs": []}
+        for xcd in (1, 0):
+            eng.set_option("fused_stack", 2)
+            eng.set_option("fused_stack_xcd", xcd)
+            eng.stack_status()
+            n0 = eng.stack_launches
+            eng.profile_enable(True)
+            got = m.reverse_diffusion(x, wav, 3, noise=z)[0]
+            _, _, _, kname = eng.profile_read_ex()
+            eng.profile_enable(False)
+            flag, _ = eng.stack_status()
+            rec["runs"].append({"xcd": xcd, "timed_out": flag, "launches": eng.stack_launches - n0,
+                                "kernel": kname.split(" ")[0], "equal": bool(torch.equal(got, ref)),
+                                "maxdiff": float((got - ref).abs().max())})
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+        with torch.no_grad():
+            spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
+            want = R.reverse_step(p, hp, sch, sampler, x, spec, 3, z, 0.5)
+        rec["vs_oracle"] = float((ref.cpu() - want).abs().max())
+        out.append(rec)
+        del m
+    print("FUSED_CASES " + json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

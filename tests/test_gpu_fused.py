@@ -1,0 +1,118 @@
+"""The fused residual-stack kernel (one persistent launch for all residual layers, group barriers between the
+phases) against one launch per phase: same device code, same MFMA order, same epilogue arithmetic, so the
+results must be BIT-IDENTICAL - any stale read across workgroups (the hazard of an in-launch hand-off) would show
+as a difference.  Both are separately held to the oracle by tests/test_gpu_parity.py; here the fused path is
+forced (fused_stack = 2) over launch geometries it would not be chosen for, so ragged tiles, multi-tile clips
+(halo exchange inside a group), tiles straddling the residual / skip halves (C = 64, 192), per-sample steps and
+both block mappings are covered."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffroll_ref as R
+from test_gpu_parity import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(m, fn, xcds=(1, 0)):
+    eng = m.engine
+    eng.set_option("fused_stack", 0)
+    ref = fn()
+    outs = []
+    for xcd in xcds:
+        eng.set_option("fused_stack", 2)
+        eng.set_option("fused_stack_xcd", xcd)
+        eng.stack_status()
+        n0 = eng.stack_launches
+        out = fn()
+        flag, _ = eng.stack_status()
+        assert flag == 0, "a group barrier of the fused kernel timed out"
+        outs.append((xcd, out, eng.stack_launches - n0))
+    eng.set_option("fused_stack", 1)
+    eng.set_option("fused_stack_xcd", 1)
+    return ref, outs
+
+
+@pytest.mark.parametrize("ni", [1, 2])
+def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
+    """All cases of tests/fused_cases.py for one frame-tile width, in a child process whose per-phase kernels are
+    pinned to the flavours the fused kernel is built from (the overrides are read once per process)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("FUSED_CASES ")][-1]
+    for rec in json.loads(line[len("FUSED_CASES "):]):
+        assert rec["vs_oracle"] <= 1e-5, rec                       # the pair is right, not just equal
+        for run in rec["runs"]:
+            assert run["timed_out"] == 0 and run["launches"] >= 1, rec
+            assert run["kernel"] == f"stack_kernel<{ni}>", rec
+            assert run["equal"], rec
+
+
+def test_fused_stack_with_per_sample_steps_and_whole_chain():
+    """forward() with a (B,) step tensor of differing entries (the step-embedding row is selected per sample inside
+    the fused kernel's 1x1 epilogues), and a whole captured chain (graph replay re-uses the in-kernel re-armed
+    counters: three replays, identical rolls)."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=128, residual_layers=4, kernel_size=9, timesteps=10)
+    p = R.synthetic_params(hp, seed=77)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    torch.manual_seed(8)
+    B, Tn = 8, 100
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    steps = torch.tensor([0, 9, 3, 3, 7, 1, 5, 2])
+    # (in this process the per-phase launches pick their own kernel flavours - split-K, 16x16 MFMA tiles - so the
+    # agreement here is fp32 round-off, not bitwise; the two block mappings of the fused kernel ARE bitwise equal)
+    ref, outs = _run_both(m, lambda: m(x, wav, steps)[0])
+    for xcd, out, launches in outs:
+        assert launches >= 1 and float((out - ref).abs().max()) <= 2e-6, xcd
+    assert torch.equal(outs[0][1], outs[1][1])
+    noise = torch.randn(hp["timesteps"], B, 1, Tn, 88)
+    ref, outs = _run_both(m, lambda: m.sample(x, wav, noise=noise)[0], xcds=(1,))
+    assert float((outs[0][1] - ref).abs().max()) <= 5e-6
+    with torch.no_grad():
+        want = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    assert float((outs[0][1].cpu() - want).abs().max()) <= 1e-5
+    m.engine.set_option("fused_stack", 2)
+    a = m.sample(x, wav, seed=4)[0]
+    b = m.sample(x, wav, seed=4)[0]
+    c = m.sample(x, wav, seed=4)[0]
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert m.engine.stack_status()[0] == 0
+
+
+def test_fused_stack_soak_under_uneven_load():
+    """Hand-offs are only trustworthy when tested with the consumers' caches warm and the chip unevenly loaded: the
+    same evaluation 40 times in a row (L1 / L2 hold the previous round's g / hd at the very same addresses), half
+    of them with a second stream hammering HBM with copies - every result must be bit-identical to the per-phase
+    reference."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_layers=3, timesteps=6)            # full width: 8 M tiles
+    p = R.synthetic_params(hp, seed=5)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    torch.manual_seed(3)
+    B, Tn = 12, 125                                       # 24 evaluations: 192 of 256 CUs, the rest idle (uneven)
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    z = torch.randn(B, 1, Tn, 88)
+    eng = m.engine
+    eng.set_option("fused_stack", 0)
+    ref = m.reverse_diffusion(x, wav, 2, noise=z)[0]
+    eng.set_option("fused_stack", 2)
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device="cuda")
+    for it in range(40):
+        if it % 2:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    big.copy_(big.flip(0))
+        out = m.reverse_diffusion(x, wav, 2, noise=z)[0]
+        assert torch.equal(out, ref), it
+    torch.cuda.synchronize()
+    assert eng.stack_status()[0] == 0
+    eng.set_option("fused_stack", 1)

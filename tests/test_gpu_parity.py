@@ -2,12 +2,15 @@
 reference and against the CPU oracle.  Needs a real MI355X: ``pytest -m gpu``.
 
 Tolerances (fp32 everywhere; the kernels use the exact-fp32 MFMA, so differences come only from
-summation order, the DFT-vs-FFT front-end and the hardware exp/rcp of the gate):
-  * one network evaluation:      atol 1e-5  (outputs are O(1); observed 2.1e-6 on the full-size net)
-  * one reverse step / chain:    atol 2e-5  (observed 2.5e-6; SURVEY.md 8c proposes 2e-5 per kernel)
-  * normalised log-mel:          atol 1e-4  (values in [0,1]; observed 2.0e-5, DFT-as-GEMM vs torch's FFT)
-  * same clips, other shard / batch geometry (other tile flavour or split-K order): atol 1e-5 (observed ~1e-6)
-i.e. 4-5x the observed margins (tests/parity_margins.py prints them): a 10x kernel regression fails.
+summation order, the FFT implementation and the hardware exp/rcp of the gate):
+  * one network evaluation:      atol 1e-5  (outputs are O(1); observed <= 2.9e-6 over the whole suite)
+  * one reverse step / chain:    atol 1e-5  (observed <= 2.9e-6; SURVEY.md 8c proposes 2e-5 per kernel)
+  * normalised log-mel:          atol 4e-5  (values in [0,1]; observed <= 8.5e-6: own FFT vs torch's, amplified by
+                                             the log at near-silent bins)
+  * same clips, other shard / batch geometry (other tile flavour or split-K order): atol 1e-5 (observed <= 2.9e-6)
+i.e. 3.4-5x the observed margins (DR_PARITY_LOG=<file> records every comparison): a 5x regression fails.
+(Until the front-end tables were built with the reference's fp32 filterbank arithmetic the log-mel differed by
+2e-5 and every conditional evaluation by up to 3e-5 - diffroll_amd/frontend_tables.py.)
 """
 import json
 import os
@@ -21,8 +24,8 @@ from oracle import diffroll_ref as R
 pytestmark = pytest.mark.gpu
 
 ATOL_FWD = 1e-5
-ATOL_STEP = 2e-5
-ATOL_SPEC = 1e-4
+ATOL_STEP = 1e-5
+ATOL_SPEC = 4e-5
 ATOL_SHARD = 1e-5
 
 

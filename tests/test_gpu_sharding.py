@@ -54,7 +54,7 @@ def test_fake_ranks_equal_unsharded(G, mode):
     if mode == "injected":                                           # and both equal the oracle's chain
         with torch.no_grad():
             ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
-        assert float((parts.cpu() - ref).abs().max()) <= 2e-5
+        assert float((parts.cpu() - ref).abs().max()) <= 1e-5
 
 
 def test_fake_ranks_generation_without_waveform():

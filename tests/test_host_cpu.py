@@ -402,3 +402,23 @@ def test_facade_rejects_unsupported_front_end_options():
         make({"n_mels": 128})
     with pytest.raises(ValueError):
         make(norm_args=[0, 1, "freqwise"])
+
+
+def test_frontend_tables_carry_the_reference_rounding():
+    """The filterbank / window the engine receives are evaluated with the reference's own fp32 expressions: equal, bit
+    for bit, to the oracle's restatement of torchaudio's melscale_fbanks (which the golden front-end vectors pin),
+    and measurably different from the exact triangles - the difference the engine must NOT smooth away."""
+    import math
+    from diffroll_amd import frontend_tables as FT
+    from oracle import diffroll_ref as R
+    w, norm, fb = FT.frontend_tables(2048, 0.0, 8000.0, 229, 16000)
+    assert torch.equal(fb, R.melscale_fbanks_htk(1025, 0.0, 8000.0, 229, 16000)) and fb.shape == (1025, 229)
+    assert torch.equal(w, torch.hann_window(2048)) and norm == float(w.pow(2.0).sum().sqrt())
+    hz2mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)             # noqa: E731
+    pts = np.array([700.0 * (10 ** ((hz2mel(0.0) + (hz2mel(8000.0) - hz2mel(0.0)) * i / 230) / 2595.0) - 1) for i in range(231)])
+    f = 8000.0 * np.arange(1025) / 1024
+    exact = np.maximum(0, np.minimum((f[:, None] - pts[None, :-2]) / (pts[1:-1] - pts[:-2])[None, :],
+                                     (pts[None, 2:] - f[:, None]) / (pts[2:] - pts[1:-1])[None, :]))
+    d = np.abs(fb.double().numpy() - exact)
+    assert 5e-6 < d.max() < 1e-4          # fp32 evaluation moves weights by ~2e-5: visible at the parity tolerance
+    assert int((fb.sum(0) == 0).sum()) == 0     # no empty filter at the released settings
