@@ -347,6 +347,24 @@ def main():
                 "thresholded_frames_differing": int(((out3 > 0.5) != (out > 0.5)).sum()),
                 "note": "opt-in precision mode; identical inputs and Philox noise as the headline run",
             }
+    if dist is not None:
+        # the same collective through the C-ABI (dr_comm_create / dr_gather: RCCL via dlopen, no torch.distributed in
+        # the data path) - run once next to the timed region and compared with torch's all-gather; reported, never
+        # allowed to fail the measurement
+        check = {}
+        try:
+            from diffroll_amd.distributed import NativeComm
+            comm = NativeComm(device)
+            roll, _ = model.sample(x_T, wav, seed=0, first_sample=rank * B)
+            a = gather_rolls(roll)
+            b = gather_rolls(roll, comm=comm)
+            torch.cuda.synchronize()
+            check = {"ok": bool(torch.equal(a, b)), "ranks": comm.world_size, "rccl_version_code": comm.rccl_version()}
+            comm.close()
+        except Exception as ex:       # noqa: BLE001
+            check = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:300]}
+        if rank == 0:
+            result["dr_gather_check"] = check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, cfg, hp)
     if rank == 0:

@@ -36,6 +36,8 @@ EXPORTS = [
     "dr_extract_x0", "dr_set_spec_norm", "dr_set_precision", "dr_profile_enable",
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
+    "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
+    "dr_gather",
 ]
 
 
@@ -118,6 +120,20 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_bench_pointwise.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.dr_debug_ticks.restype = C.c_int
     lib.dr_debug_ticks.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.dr_rccl_version.restype = C.c_int
+    lib.dr_rccl_version.argtypes = [C.POINTER(C.c_int)]
+    lib.dr_comm_unique_id.restype = C.c_int
+    lib.dr_comm_unique_id.argtypes = [C.c_char_p]
+    lib.dr_comm_create.restype = C.c_int
+    lib.dr_comm_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, C.c_int]
+    lib.dr_comm_destroy.restype = None
+    lib.dr_comm_destroy.argtypes = [vp]
+    lib.dr_comm_info.restype = C.c_int
+    lib.dr_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.dr_comm_last_error.restype = C.c_char_p
+    lib.dr_comm_last_error.argtypes = []
+    lib.dr_gather.restype = C.c_int
+    lib.dr_gather.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp]
     if lib.dr_abi_version() != DR_ABI_VERSION:
         raise RuntimeError("libdiffroll_amd.so ABI version mismatch: rebuild it")
     _lib = lib

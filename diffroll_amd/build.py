@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffroll_amd.so")
-SOURCES = ["kernels.hip", "engine.hip"]
+SOURCES = ["kernels.hip", "engine.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "diffroll_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

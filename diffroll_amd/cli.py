@@ -10,8 +10,8 @@ Hydra is not a dependency: the same ``group=name`` / ``dotted.key=value`` overri
 defaults that restate config/sampling.yaml, config/task/{generation,transcription,inpainting}.yaml,
 config/model/ClassifierFreeDiffRoll.yaml and config/spec/mel.yaml.  Differences from the reference driver:
 no Lightning Trainer / TensorBoard; rolls are written as ``rolls_batch<i>.npy`` plus ``raw_midi_<batch>_<i>.mid`` / ``clean_midi_e<batch>_<i>.mid``;
-audio ingestion (utils/custom_dataset.py:55-91) reads .wav only (no mp3 codec in this image) and resamples with
-scipy's polyphase filter instead of torchaudio's windowed-sinc kernel.
+audio ingestion (utils/custom_dataset.py:55-91) reads .wav only (no mp3 codec in this image); resampling restates
+torchaudio 0.11's windowed-sinc kernel (diffroll_amd/audio.py).
 """
 from __future__ import annotations
 
@@ -97,29 +97,15 @@ def build_config(argv: List[str], default_task: str = "generation") -> Dict[str,
 
 
 def load_wav_folder(args: Dict[str, Any]) -> torch.Tensor:
-    """utils/custom_dataset.py:55-91: mono mix, resample to sample_rate, crop / zero-pad to max_segment_samples."""
-    from scipy.io import wavfile
-    from scipy.signal import resample_poly
+    """utils/custom_dataset.py:55-91 over a folder: mono mix, torchaudio-0.11 windowed-sinc resampling, crop /
+    zero-pad to max_segment_samples (diffroll_amd/audio.py)."""
+    from .audio import ingest
     if str(args["audio_ext"]).lower() != "wav":
         raise SystemExit("only .wav can be decoded in this environment (no mp3/flac codec)")
     files = sorted(glob.glob(os.path.join(args["audio_path"], f"*.{args['audio_ext']}")))
     if not files:
         raise SystemExit(f"no *.{args['audio_ext']} files under {args['audio_path']}")
-    out = []
-    for f in files:
-        rate, data = wavfile.read(f)
-        x = data.astype(np.float32)
-        if np.issubdtype(data.dtype, np.integer):
-            x /= float(np.iinfo(data.dtype).max + 1)
-        if x.ndim == 2:
-            x = x.mean(1) if x.shape[1] == 2 else x[:, 0]
-        if rate != args["sample_rate"]:
-            g = np.gcd(int(rate), int(args["sample_rate"]))
-            x = resample_poly(x, args["sample_rate"] // g, rate // g).astype(np.float32)
-        n = int(args["max_segment_samples"])
-        x = x[:n] if len(x) >= n else np.pad(x, (0, n - len(x)))
-        out.append(torch.from_numpy(x))
-    return torch.stack(out)
+    return torch.stack([ingest(f, int(args["sample_rate"]), int(args["max_segment_samples"])) for f in files])
 
 
 def make_model(cfg: Dict[str, Any], device):

@@ -1,0 +1,141 @@
+// RCCL behind the C-ABI: the one collective of the path - the all-gather of the finished rolls over xGMI
+//  - for callers that have no torch.distributed.  librccl is looked up at run time (dlopen): the
+// engine library has no link-time dependency on it, and a process that already carries an RCCL (PyTorch loads its
+// own copy) shares that one.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/diffroll_amd.h"
+
+namespace {
+
+constexpr int kUniqueIdBytes = 128;                 // NCCL_UNIQUE_ID_BYTES (rccl.h)
+struct UniqueId { char internal[kUniqueIdBytes]; };  // ncclUniqueId: passed BY VALUE to ncclCommInitRank
+typedef void* Comm;                                  // ncclComm_t
+constexpr int kFloat32 = 7;                          // ncclFloat32
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+    Rccl() {
+        // an RCCL already in the process (torch's) first, then the ROCm installation's
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+            if (lib) break;
+        }
+        if (!lib)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (lib) break;
+            }
+        if (!lib) { why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* n) { return dlsym(lib, n); };
+        GetVersion = reinterpret_cast<int (*)(int*)>(sym("ncclGetVersion"));
+        GetUniqueId = reinterpret_cast<int (*)(UniqueId*)>(sym("ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<int (*)(Comm*, int, UniqueId, int)>(sym("ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<int (*)(Comm)>(sym("ncclCommDestroy"));
+        AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, Comm, hipStream_t)>(sym("ncclAllGather"));
+        GetErrorString = reinterpret_cast<const char* (*)(int)>(sym("ncclGetErrorString"));
+        if (!GetVersion || !GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) {
+            why = "librccl lacks an expected symbol";
+            lib = nullptr;
+        }
+    }
+};
+Rccl& rccl() { static Rccl r; return r; }
+
+thread_local std::string g_comm_error;
+int cfail(int code, const std::string& msg) { g_comm_error = msg; return code; }
+std::string nccl_err(const char* what, int rc) {
+    return std::string(what) + " failed: " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?");
+}
+
+}  // namespace
+
+struct dr_comm {
+    Comm comm = nullptr;
+    int n_ranks = 0, rank = 0, device = 0;
+};
+
+extern "C" {
+
+const char* dr_comm_last_error(void) { return g_comm_error.c_str(); }
+
+int dr_rccl_version(int* version) {
+    if (!version) return cfail(DR_EINVAL, "null argument");
+    if (!rccl().lib) return cfail(DR_ESTATE, rccl().why);
+    int rc = rccl().GetVersion(version);
+    return rc ? cfail(DR_EHIP, nccl_err("ncclGetVersion", rc)) : DR_OK;
+}
+
+int dr_comm_unique_id(char* id_out) {
+    if (!id_out) return cfail(DR_EINVAL, "null argument");
+    if (!rccl().lib) return cfail(DR_ESTATE, rccl().why);
+    UniqueId id;
+    int rc = rccl().GetUniqueId(&id);
+    if (rc) return cfail(DR_EHIP, nccl_err("ncclGetUniqueId", rc));
+    memcpy(id_out, id.internal, kUniqueIdBytes);
+    return DR_OK;
+}
+
+int dr_comm_create(dr_comm** out, const char* id, int n_ranks, int rank, int device) {
+    if (!out || !id) return cfail(DR_EINVAL, "null argument");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return cfail(DR_EINVAL, "bad rank / world size");
+    if (!rccl().lib) return cfail(DR_ESTATE, rccl().why);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return cfail(DR_EINVAL, "device " + std::to_string(device) + " out of range");
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(device) != hipSuccess) return cfail(DR_EHIP, "hipSetDevice failed");
+    UniqueId uid;
+    memcpy(uid.internal, id, kUniqueIdBytes);
+    Comm c = nullptr;
+    int rc = rccl().CommInitRank(&c, n_ranks, uid, rank);       // collective: every rank of the job calls it
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (rc) return cfail(DR_EHIP, nccl_err("ncclCommInitRank", rc));
+    dr_comm* h = new dr_comm();
+    h->comm = c; h->n_ranks = n_ranks; h->rank = rank; h->device = device;
+    *out = h;
+    return DR_OK;
+}
+
+void dr_comm_destroy(dr_comm* c) {
+    if (!c) return;
+    if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank) {
+    if (!c) return cfail(DR_EINVAL, "null argument");
+    if (n_ranks) *n_ranks = c->n_ranks;
+    if (rank) *rank = c->rank;
+    return DR_OK;
+}
+
+int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, int B_local, int T, void* stream) {
+    (void)e;                                    // no engine state is involved; kept for a uniform call shape
+    if (!comm || !d_shard || !d_full) return cfail(DR_EINVAL, "null argument");
+    if (B_local < 0 || T <= 0) return cfail(DR_EINVAL, "bad shape");
+    if (B_local == 0) return DR_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (prev != comm->device && hipSetDevice(comm->device) != hipSuccess) return cfail(DR_EHIP, "hipSetDevice failed");
+    int rc = rccl().AllGather(d_shard, d_full, (size_t)B_local * T * 88, kFloat32, comm->comm, (hipStream_t)stream);
+    if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev);
+    return rc ? cfail(DR_EHIP, nccl_err("ncclAllGather", rc)) : DR_OK;
+}
+
+}  // extern "C"

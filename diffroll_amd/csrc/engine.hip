@@ -112,6 +112,7 @@ struct dr_engine {
     // launch is resident at once; opt_stack 0 = always one launch per phase
     int opt_stack = 1;
     int opt_stack_xcd = 1;              // group-per-XCD block mapping (0: weight-panel-per-XCD)
+    int opt_stack_warm = 0;             // idle waves of the fused kernel warm the L2 for the next phase (measured: +-0)
     int n_cus = 0;
     unsigned* stack_bar = nullptr;      // [STACK_GROUPS][2] group counters, zero between launches
     unsigned* stack_err = nullptr;
@@ -525,6 +526,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         sa.c_bs = (long)2 * Cp * T;
         sa.p0 = p0; sa.p1 = p1;
         sa.xcd_n = e->opt_stack_xcd;
+        sa.warm = e->opt_stack_warm;
         sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
         sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
         int maxdil = 1;
@@ -1346,6 +1348,7 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
     };
     if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
     if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
+    if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop_graph(); e->opt_stack_warm = value; return DR_OK; }
     if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop_graph(); e->stack_dbg_on = value; return DR_OK; }
     return fail(e, DR_ENAME, "unknown option '%s'", name);
 }

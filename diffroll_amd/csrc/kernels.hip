@@ -1015,6 +1015,23 @@ hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s) {
 // replayed graph needs no memset node.  Spins are bounded: a wait that runs into the bound sets *err and
 // carries on (wrong data, but no hung queue).
 // ---------------------------------------------------------------------------------------------
+// L2 warm-up by a wave that has nothing else to do (the conv's producer waves once their last X tile is staged;
+// all four of them during a 1x1 phase): touch one dword of every 128-byte line of [base, base + bytes) so that the
+// consumers' first fragment / epilogue-operand loads of the NEXT phase hit the XCD's L2 instead of HBM.  part / parts
+// split the range over the helper waves.  The loaded values are folded into a register the compiler must
+// materialise (the empty asm), nothing else depends on them.
+DR_DEVINL void l2_touch(const float* base, const unsigned bytes, const int part, const int parts) {
+    if (!base || !bytes) return;
+    typedef unsigned u32;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    u32 acc = 0;
+#pragma unroll 8
+    for (unsigned off = (unsigned)part * 8192u + (unsigned)lane * 128u; off < bytes; off += (unsigned)parts * 8192u)
+        acc ^= __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0);
+    asm volatile("" ::"v"(acc));
+}
+
 template <bool ACQUIRE>
 DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave: its stores (incl. the asm sc1 ones) are out
@@ -1126,6 +1143,15 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
             gemm_body<NI, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
+            if (wave >= 4 && s.warm) {
+                // the producers are back while the consumers still contract the last chunk (~16 us at k = 9): warm
+                // the L2 with what comes next - this block's conditioner tile (read by the gate epilogue: 32 planes x
+                // T x 16 B, contiguous) and the weight panel of the 1x1 phase that follows (128 rows x Cp x 4 B)
+                const int be = nt / tps;
+                if (be < s.n_cond)
+                    l2_touch(ly.cond + (long)be * s.c_bs + (long)mt * 32 * s.T * 4, (unsigned)(32 * s.T * 16), wave - 4, 4);
+                l2_touch(ly.out_w + (long)mt * (s.Cp >> 5) * 4096, (unsigned)((s.Cp >> 5) * 16384), wave - 4, 4);
+            }
         } else {
             a.Wp = ly.out_w; a.bias = ly.out_b;
             a.X = s.g; a.taps = 1; a.dil = 1;
@@ -1141,6 +1167,12 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             const bool idle = last && mt < (s.Cp >> 7);
             if (s.dbg && p + 3 == s.p1) a.dbg = s.dbg + 96;       // second-to-last 1x1 phase (block 0 works in it)
             if (wave < 4 && !idle) pw_body<2 * NI, 1, 1>(a, mt, nt, wave, Rs);
+            if (wave >= 4 && s.warm && !last) {
+                // idle for the whole 1x1 phase: fetch the first two chunks (2 x taps slabs of 16 KB) of the next
+                // layer's conv weight panel of this M tile
+                const __attribute__((address_space(4))) StackLayer& nx = sp->layer[l + 1];
+                l2_touch(nx.conv_w + (long)mt * (s.Cp >> 5) * s.taps * 4096, (unsigned)(2 * s.taps * 16384), wave - 4, 4);
+            }
         }
         if (p + 1 < s.p1) {
             // the phase after an even one is a 1x1: its plain g loads need the acquire; a conv phase reads hd

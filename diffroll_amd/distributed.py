@@ -31,8 +31,11 @@ def shard_bounds(n: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_rolls(local: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather equally sized local rolls (b, 1, T, 88) into (world*b, 1, T, 88), rank-major."""
+def gather_rolls(local: torch.Tensor, group=None, comm: Optional["NativeComm"] = None) -> torch.Tensor:
+    """All-gather equally sized local rolls (b, 1, T, 88) into (world*b, 1, T, 88), rank-major: through
+    torch.distributed (backend 'nccl' = RCCL), or through the C-ABI's dr_gather when a NativeComm is given."""
+    if comm is not None:
+        return comm.all_gather(local)
     d = _dist()
     if d is None:
         return local
@@ -41,6 +44,73 @@ def gather_rolls(local: torch.Tensor, group=None) -> torch.Tensor:
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     d.all_gather_into_tensor(out, local, group=group)
     return out
+
+
+class NativeComm:
+    """An RCCL communicator reached through the C-ABI (dr_comm_create / dr_gather, include/diffroll_amd.h): what a
+    caller WITHOUT torch.distributed uses for the path's one collective.  Here it is created next to an existing
+    torch process group only to hand the 128-byte unique id from rank 0 to the others (any side channel would do -
+    a file, MPI, a socket); the all-gather itself runs in librccl via the engine library, on the caller's stream."""
+
+    def __init__(self, device: torch.device, rank: Optional[int] = None, world_size: Optional[int] = None,
+                 unique_id: Optional[bytes] = None, group=None):
+        import ctypes as C
+        from . import _cabi
+        self.lib = _cabi.load_library()
+        self.device = torch.device(device)
+        d = _dist()
+        if rank is None or world_size is None:
+            rank, world_size = (d.get_rank(group), d.get_world_size(group)) if d else (0, 1)
+        if unique_id is None:
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                if self.lib.dr_comm_unique_id(buf) != 0:
+                    raise RuntimeError("dr_comm_unique_id: " + self.lib.dr_comm_last_error().decode())
+                unique_id = buf.raw
+            if world_size > 1:
+                if d is None:
+                    raise ValueError("unique_id is required on every rank when no torch process group exists")
+                box = [unique_id]
+                d.broadcast_object_list(box, src=0, group=group)
+                unique_id = box[0]
+        assert isinstance(unique_id, (bytes, bytearray)) and len(unique_id) == 128
+        self.rank, self.world_size = rank, world_size
+        h = C.c_void_p()
+        rc = self.lib.dr_comm_create(C.byref(h), bytes(unique_id), world_size, rank, self.device.index or 0)
+        if rc != 0:
+            raise RuntimeError(f"dr_comm_create failed ({rc}): " + self.lib.dr_comm_last_error().decode())
+        self.h = h
+
+    def rccl_version(self) -> int:
+        import ctypes as C
+        v = C.c_int(0)
+        if self.lib.dr_rccl_version(C.byref(v)) != 0:
+            raise RuntimeError(self.lib.dr_comm_last_error().decode())
+        return int(v.value)
+
+    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
+        """(b, 1, T, 88) or (b, T, 88) fp32 on the communicator's device -> (world * b, ...), rank-major."""
+        local = local.contiguous()
+        assert local.device == self.device and local.dtype == torch.float32 and local.shape[-1] == 88
+        b, T = local.shape[0], local.shape[-2]
+        out = torch.empty((self.world_size * b,) + tuple(local.shape[1:]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.dr_gather(None, self.h, local.data_ptr(), out.data_ptr(), b, T,
+                                    torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"dr_gather failed ({rc}): " + self.lib.dr_comm_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dr_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
 
 def unpad_gathered(full: torch.Tensor, n_total: int, world_size: int) -> torch.Tensor:

@@ -259,6 +259,9 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          also launches that fill less than half the chip (tests).
  *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
  *                          0 = one weight panel per XCD.  Performance only.
+ *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that
+ *                          they are L2-resident when needed.  Performance only (measured: no gain, 888.4 vs 887.2 ms
+ *                          per config-2 chain - the loads it would speed up are already hidden).
  *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
  */
 int dr_set_option(dr_engine* e, const char* name, int value);
@@ -277,6 +280,28 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream);
 /* s_memtime ticks (shader clock) block 0 of the last dr_bench_layer launch spent in its K loop / in
  * total: with the wall time this gives the effective clock the kernel ran at. */
 int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks);
+
+/*
+ * Multi-GPU: the path shards by clips - one process per GPU, every rank runs its contiguous shard of
+ * the batch with dr_sample (first_sample = the shard's global offset, so Philox noise does not depend on the world
+ * size) and the ONLY collective is one all-gather of the finished rolls over xGMI.  These entry points give a
+ * caller without torch.distributed that collective: RCCL (librccl, looked up with dlopen at first use).
+ * The reference reaches N GPUs through Lightning's Trainer(gpus=N) (sampling.py:70) and never gathers.
+ *   dr_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank by any side channel
+ *   dr_comm_create      every rank, collectively: ncclCommInitRank on `device`
+ *   dr_gather           d_shard (B_local, T, 88) of every rank -> d_full (n_ranks * B_local, T, 88), rank-major, on
+ *                       `stream` (ncclAllGather; equal B_local on all ranks - pad uneven shards, see
+ *                       diffroll_amd/distributed.py).  `e` may be NULL.
+ * Errors of these functions: dr_comm_last_error().
+ */
+typedef struct dr_comm dr_comm;
+int dr_rccl_version(int* version);
+int dr_comm_unique_id(char* id_out /* 128 bytes */);
+int dr_comm_create(dr_comm** out, const char* id /* 128 bytes */, int n_ranks, int rank, int device);
+void dr_comm_destroy(dr_comm* c);
+int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank);
+const char* dr_comm_last_error(void);
+int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, int B_local, int T, void* stream);
 
 #ifdef __cplusplus
 }

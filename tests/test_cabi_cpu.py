@@ -110,3 +110,21 @@ def test_header_is_plain_c_and_links(lib, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "ABI version mismatch" in r.stdout
+
+
+def test_comm_entry_points_fail_cleanly_without_a_gpu():
+    """The RCCL half of the ABI: librccl is found by dlopen (version readable), and creating a communicator on a box
+    with no HIP device is an error code + message, not a crash."""
+    import ctypes as C
+    from diffroll_amd import _cabi
+    import torch
+    lib = _cabi.load_library()
+    v = C.c_int(0)
+    rc = lib.dr_rccl_version(C.byref(v))
+    assert (rc == 0 and v.value > 20000) or (rc != 0 and lib.dr_comm_last_error())
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert lib.dr_comm_create(C.byref(h), b"\0" * 128, 1, 0, 0) == _cabi.DR_EINVAL
+        assert b"out of range" in lib.dr_comm_last_error() and not h.value
+    assert lib.dr_comm_create(None, None, 1, 0, 0) == _cabi.DR_EINVAL
+    assert lib.dr_gather(None, None, None, None, 1, 1, None) == _cabi.DR_EINVAL

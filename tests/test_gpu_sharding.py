@@ -143,3 +143,19 @@ def test_bench_refuses_more_gpus_than_visible():
     assert r.returncode != 0
     msg = r.stdout + r.stderr
     assert f"only {n} HIP device" in msg and "torch.distributed.run" not in msg.split("only")[0][-200:], msg[-1000:]
+
+
+def test_native_comm_one_rank_gather_through_the_cabi():
+    """dr_comm_unique_id -> dr_comm_create (ncclCommInitRank, 1 rank) -> dr_gather (ncclAllGather) on the device, no
+    torch.distributed anywhere: the gathered tensor equals the shard; the library reports its RCCL version."""
+    from diffroll_amd.distributed import NativeComm, gather_rolls
+    dev = torch.device("cuda", 0)
+    comm = NativeComm(dev, rank=0, world_size=1)
+    assert comm.rccl_version() > 20000
+    x = torch.randn(5, 1, 37, 88, device=dev)
+    y = gather_rolls(x, comm=comm)
+    torch.cuda.synchronize()
+    assert y.shape == x.shape and torch.equal(y, x)
+    z = comm.all_gather(x[:, 0].contiguous())
+    assert torch.equal(z, x[:, 0])
+    comm.close()

@@ -422,3 +422,45 @@ def test_frontend_tables_carry_the_reference_rounding():
     d = np.abs(fb.double().numpy() - exact)
     assert 5e-6 < d.max() < 1e-4          # fp32 evaluation moves weights by ~2e-5: visible at the parity tolerance
     assert int((fb.sum(0) == 0).sum()) == 0     # no empty filter at the released settings
+
+
+def test_resample_restates_torchaudio_011_windowed_sinc():
+    """diffroll_amd.audio.resample = torchaudio.functional.resample with the 0.11 defaults (utils/custom_dataset.py:62):
+    checked against an independent scalar evaluation of the published kernel formula, and by properties (length,
+    identity, DC gain, pass-band sine, stop-band rejection, linearity).  torchaudio itself is absent: unpinned."""
+    import math
+    from diffroll_amd import audio as A
+    # kernel bank vs a scalar float64 evaluation of the formula, 3 -> 2 (orig 3, new 2, rolloff 0.99, width 6)
+    bank, width, orig, new = A.sinc_resample_kernel(48000, 32000)
+    assert (orig, new) == (3, 2)
+    base = 2 * 0.99
+    assert width == math.ceil(6 * 3 / base) and bank.shape == (2, 1, 2 * width + 3)
+    for i in range(new):
+        for j, n in enumerate(range(-width, width + orig)):
+            t = max(-6.0, min(6.0, (-i / new + n / orig) * base))
+            win = math.cos(t * math.pi / 6 / 2) ** 2
+            s = 1.0 if t == 0 else math.sin(t * math.pi) / (t * math.pi)
+            assert abs(float(bank[i, 0, j]) - s * win * base / orig) < 1e-7
+    assert abs(float(A.sinc_resample_kernel(1, 2)[0][0, 0, 7]) - 0.99) < 1e-7      # centre tap = rolloff (scale * sinc(0))
+    # length = ceil(new * L / orig); same rate is the identity (same object, as torchaudio)
+    x = torch.randn(2, 1001)
+    assert A.resample(x, 44100, 16000).shape == (2, math.ceil(160 * 1001 / 441))
+    assert A.resample(x, 16000, 16000) is x
+    # DC gain ~ 1, linearity exact up to fp32 rounding
+    dc = A.resample(torch.ones(4000), 22050, 16000)[100:-100]
+    assert float((dc - 1).abs().max()) < 2e-3
+    y = torch.randn(1001)
+    lin = A.resample(2 * x[0] + y, 8000, 16000) - (2 * A.resample(x[0], 8000, 16000) + A.resample(y, 8000, 16000))
+    assert float(lin.abs().max()) < 1e-5
+    # a 440 Hz + 3 kHz mixture survives 44.1k -> 16k; a 10 kHz tone (above the new Nyquist) is rejected
+    t0 = torch.arange(44100) / 44100
+    t1 = torch.arange(16000) / 16000
+    mix = A.resample(0.5 * torch.sin(2 * math.pi * 440 * t0) + 0.2 * torch.sin(2 * math.pi * 3000 * t0), 44100, 16000)
+    want = 0.5 * torch.sin(2 * math.pi * 440 * t1) + 0.2 * torch.sin(2 * math.pi * 3000 * t1)
+    assert float((mix - want)[200:-200].abs().max()) < 2e-3
+    assert float(A.resample(torch.sin(2 * math.pi * 10000 * t0), 44100, 16000)[200:-200].pow(2).mean().sqrt()) < 1e-2
+    # mono rule of the reference: mean of exactly two channels, else the first channel
+    st = torch.stack([torch.ones(5), torch.zeros(5)])
+    assert torch.equal(A.to_mono(st), torch.full((5,), 0.5))
+    assert torch.equal(A.to_mono(torch.stack([torch.ones(5), torch.zeros(5), torch.zeros(5)])), torch.ones(5))
+    assert A.crop_or_pad(torch.ones(3), 5).tolist() == [1, 1, 1, 0, 0] and A.crop_or_pad(torch.ones(7), 5).shape == (5,)

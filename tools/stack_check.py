@@ -94,13 +94,15 @@ def main():
 
     eng.set_option("fused_stack", 0)
     t_un, r_un = chain_ms()
-    for xcd in (1, 0):
+    for xcd, warm in ((1, 1), (1, 0), (0, 1)):
         eng.set_option("fused_stack", 1)
         eng.set_option("fused_stack_xcd", xcd)
+        eng.set_option("fused_stack_warm", warm)
         t_f, r_f = chain_ms()
         flag, _ = eng.stack_status()
-        print(f"chain: unfused {t_un:.1f} ms, fused(xcd={xcd}) {t_f:.1f} ms ({100 * (t_un - t_f) / t_un:+.2f} %), "
+        print(f"chain: unfused {t_un:.1f} ms, fused(xcd={xcd}, warm={warm}) {t_f:.1f} ms ({100 * (t_un - t_f) / t_un:+.2f} %), "
               f"bitwise equal rolls: {bool(torch.equal(r_un, r_f))}, timed_out={flag}", flush=True)
+    eng.set_option("fused_stack_warm", 0)
     return 0
 
 
