@@ -1,34 +1,52 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence under profiles/ - run ON THE GPU BOX:
-#     gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh gpurun_out/prof'
-# then copy gpurun_out/prof/r01_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter
-# set per pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
+#     gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02 gpurun_out/prof'
+# then copy gpurun_out/prof/<round>_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter set per
+# pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
 set -u
+RD=${1:-r02}
 R=$PWD
-OUT=$R/${1:-gpurun_out/prof}
+OUT=$R/${2:-gpurun_out/prof}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/bench_kt.log" 2>&1
-echo "rc=$?"
-python "$R/tools/prof_summary.py" "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip(1x1) 5 power 6 log; PREC 1 = split-bf16 rows of the extra split_bf16x3 measurement; pw_kernel<NW> = 1x1 residual/skip GEMM, fp32)" > "$OUT/r01_kernel_stats.txt"
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf" -o pf -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pf.log" 2>&1
-echo "rc=$?"
-python "$R/tools/prof_summary.py" "$OUT/pf" pf "rocprofv3 --pmc FETCH_SIZE -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_fetch.txt"
-timeout 300 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pw" -o pw -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pw.log" 2>&1
-echo "rc=$?"
-python "$R/tools/prof_summary.py" "$OUT/pw" pw "rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_write.txt"
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pm" -o pm -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pm.log" 2>&1
-echo "rc=$?"
-python "$R/tools/prof_summary.py" "$OUT/pm" pm "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_mfma.txt"
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pl" -o pl -- python "$R/tools/layer_bench.py" --iters 10 --layers 1,3 > "$OUT/pl.log" 2>&1
-echo "rc=$?"
-python "$R/tools/prof_summary.py" "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/layer_bench.py --iters 10 --layers 1,3" > "$OUT/r01_conv_pmc_lds.txt"
+PS="python $R/tools/prof_summary.py"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_kt.log" 2>&1
+echo "kernel trace rc=$?"
+$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split (MI355X, config 2; stack_kernel<NI> = fused residual stack: 14 dilated convs + 15 1x1 per launch; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log; the gemm_kernel<..,3,..> rows here are layer 0's conv + the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
+for cfg in 2 3; do
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
+echo "fetch cfg$cfg rc=$?"
+timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pw$cfg" -o pw -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pw$cfg.log" 2>&1
+echo "write cfg$cfg rc=$?"
+python "$R/tools/make_traffic_json.py" "$OUT/pf$cfg" "$OUT/pw$cfg" $cfg "$OUT/${RD}_stack_cfg${cfg}_traffic.json"
+done
+$PS "$OUT/pf2" pf "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_fetch.txt"
+$PS "$OUT/pw2" pw "rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_write.txt"
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pm" -o pm -- python "$R/tools/step_loop.py" --config 2 --iters 10 > "$OUT/pm.log" 2>&1
+echo "mfma rc=$?"
+$PS "$OUT/pm" pm "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_mfma.txt"
+timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pl" -o pl -- python "$R/tools/step_loop.py" --config 2 --iters 10 > "$OUT/pl.log" 2>&1
+echo "lds rc=$?"
+$PS "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_lds.txt"
 cd "$R"
-timeout 600 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-echo "rc=$?"
-timeout 600 python tools/config_bench.py > "$OUT/r01_config_bench.txt" 2>&1
-rm -rf "$OUT/kt" "$OUT/pf" "$OUT/pw" "$OUT/pm" "$OUT/pl"
-grep -A3 "gemm_kernel<2, 1, 3, 0>" "$OUT/r01_conv_pmc_fetch.txt" "$OUT/r01_conv_pmc_write.txt" "$OUT/r01_conv_pmc_mfma.txt" | grep -v "^--" | head -30
-head -12 "$OUT/r01_kernel_stats.txt"
-cat "$OUT/bench.json" "$OUT/r01_config_bench.txt"
+mkdir -p profiles_tmp && cp "$OUT"/${RD}_stack_cfg*_traffic.json profiles/ 2>/dev/null   # so that bench.py finds the stamped record
+for c in 1 2 3 4 5; do
+  extra="--no-split --no-cpu-baseline"; [ $c = 2 ] && extra=""
+  timeout 900 python bench.py --config $c $extra > "$OUT/${RD}_bench_cfg$c.json" 2> "$OUT/bench_cfg$c.err"; echo "bench cfg$c rc=$?"
+done
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
+rm -rf "$OUT/kt" "$OUT/pf2" "$OUT/pw2" "$OUT/pf3" "$OUT/pw3" "$OUT/pm" "$OUT/pl" profiles_tmp
+head -14 "$OUT/${RD}_kernel_stats.txt"
+cat "$OUT"/${RD}_stack_cfg*_traffic.json
+grep -A8 "stack_kernel" "$OUT/${RD}_stack_pmc_mfma.txt" | head -12
+for c in 1 2 3 4 5; do python - "$OUT/${RD}_bench_cfg$c.json" <<'PY'
+import json,sys
+try:
+    j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r=j.get("roofline",{})
+    print(sys.argv[1].split("/")[-1], j["value"], j["ms_per_step"], "roofline", r.get("frac"), "traffic", r.get("traffic"), r.get("traffic_source"), j.get("whole_chain",{}).get("frac_of_fp32_mfma_peak"), j.get("hbm_roofline",{}).get("frac"))
+except Exception as e:
+    print("ERR", sys.argv[1], e)
+PY
+done
