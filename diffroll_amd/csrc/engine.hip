@@ -112,10 +112,12 @@ struct dr_engine {
     // launch is resident at once; opt_stack 0 = always one launch per phase
     int opt_stack = 1;
     int opt_stack_xcd = 1;              // group-per-XCD block mapping (0: weight-panel-per-XCD)
+    int opt_stack_fault = 0;            // test hook (option "stack_fault_test")
     int opt_stack_warm = 0;             // idle waves of the fused kernel warm the L2 for the next phase (measured: +-0)
     int n_cus = 0;
     unsigned* stack_bar = nullptr;      // [STACK_GROUPS][2] group counters, zero between launches
-    unsigned* stack_err = nullptr;
+    unsigned* stack_err = nullptr;      // device address of the time-out flag (host-mapped memory)
+    volatile unsigned* stack_err_host = nullptr;
     unsigned* stack_xid = nullptr;      // [n_cus-sized] XCC ids published by the blocks of the last launch
     long long* stack_dbg = nullptr;     // phase tick marks of block 0 (dr_debug_stack_ticks)
     int stack_dbg_on = 0;
@@ -527,6 +529,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         sa.p0 = p0; sa.p1 = p1;
         sa.xcd_n = e->opt_stack_xcd;
         sa.warm = e->opt_stack_warm;
+        sa.fault = e->opt_stack_fault;
         sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
         sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
         int maxdil = 1;
@@ -683,6 +686,10 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
 
 int check_ready(dr_engine* e, int sampler, int B, int T) {
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    if (e->stack_err_host && *e->stack_err_host)
+        return fail(e, DR_EHIP, "a group barrier of an earlier fused residual-stack launch timed out (its results are invalid): "
+                                "is another stream / engine computing on this device at the same time? set option "
+                                "fused_stack = 0 for that, and call dr_stack_status to clear the condition");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
     if (sampler != DR_SAMPLER_GENERATION_DDPM_X0 && (e->fe_B != B || e->fe_T != T))
         return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
@@ -772,6 +779,7 @@ void dr_destroy(dr_engine* e) {
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
     if (e->stack_bar) (void)hipFree(e->stack_bar);
+    if (e->stack_err_host) (void)hipHostFree((void*)e->stack_err_host);
     if (e->stack_dbg) (void)hipFree(e->stack_dbg);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
     if (e->d_tsel) (void)hipFree(e->d_tsel);
@@ -1003,12 +1011,20 @@ int dr_commit(dr_engine* e, void* stream) {
     if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
     if (!e->stack_bar) {     // group counters of the fused residual stack: zero between launches (re-armed in-kernel)
         void* q = nullptr;
-        const size_t nb = (size_t)(2 * dr_engine::STACK_GROUPS + 4 + 1024) * sizeof(unsigned);
+        const size_t nb = (size_t)(2 * dr_engine::STACK_GROUPS + 1024) * sizeof(unsigned);
         HIPCHK(e, hipMalloc(&q, nb));
         HIPCHK(e, hipMemset(q, 0, nb));
         e->stack_bar = (unsigned*)q;
-        e->stack_err = e->stack_bar + 2 * dr_engine::STACK_GROUPS;
-        e->stack_xid = e->stack_err + 4;                      // one word per block (<= 1024 CUs)
+        e->stack_xid = e->stack_bar + 2 * dr_engine::STACK_GROUPS;      // one word per block (<= 1024 CUs)
+        // the "a barrier wait gave up" flag lives in host-visible memory: every later API call sees it without a
+        // synchronisation and fails loudly instead of returning rolls computed from a broken hand-off
+        void* hf = nullptr;
+        HIPCHK(e, hipHostMalloc(&hf, 64, hipHostMallocMapped));
+        memset(hf, 0, 64);
+        e->stack_err_host = (volatile unsigned*)hf;
+        void* df = nullptr;
+        HIPCHK(e, hipHostGetDevicePointer(&df, hf, 0));
+        e->stack_err = (unsigned*)df;
         void* d = nullptr;
         HIPCHK(e, hipMalloc(&d, 128 * sizeof(long long)));
         HIPCHK(e, hipMemset(d, 0, 128 * sizeof(long long)));
@@ -1349,6 +1365,7 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
     if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
     if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
     if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop_graph(); e->opt_stack_warm = value; return DR_OK; }
+    if (n == "stack_fault_test") { if (e->opt_stack_fault != value) drop_graph(); e->opt_stack_fault = value; return DR_OK; }
     if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop_graph(); e->stack_dbg_on = value; return DR_OK; }
     return fail(e, DR_ENAME, "unknown option '%s'", name);
 }
@@ -1358,12 +1375,12 @@ int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t
     if (!e->stack_bar) return fail(e, DR_ESTATE, "dr_commit has not been called");
     DeviceGuard guard(e->cfg.device);
     HIPCHK(e, hipDeviceSynchronize());
-    unsigned flag = 0;
-    HIPCHK(e, hipMemcpy(&flag, e->stack_err, sizeof flag, hipMemcpyDeviceToHost));
+    const unsigned flag = *e->stack_err_host;
     if (timed_out) *timed_out = (int32_t)flag;
     if (launches) *launches = e->stack_launches;
     if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
-        HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(2 * dr_engine::STACK_GROUPS + 4) * sizeof(unsigned)));
+        HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(2 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));
+        *e->stack_err_host = 0;
     }
     if (ticks && n_ticks > 0) {
         long long h[128];

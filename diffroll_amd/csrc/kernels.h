@@ -125,6 +125,7 @@ struct StackArgs {
     int p0, p1;                               // phases [p0, p1)
     int xcd_n;                                // block -> (M tile, frame tile) mapping, as in gemm_kernel
     int rs_off;                               // set by the launcher: LDS byte offset of the resident h / skip tile
+    int fault;                                // test hook: barriers wait for one arrival too many (exercises the spin bound)
     int warm;                                 // idle waves warm the L2 with the next phase's weights / conditioner tile
     unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)
     unsigned* bar;                            // [groups][2] arrival / departure counters, all zero between launches

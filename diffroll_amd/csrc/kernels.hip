@@ -1042,8 +1042,9 @@ DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(4);
             // ~1 s of polling (a phase lasts < 1 ms), or another wait already gave up: flag it and carry on
-            if (++spins > (1u << 20) || ((spins & 1023u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (*err is host-mapped memory: system scope)
+            if (++spins > (1u << 20) || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -1177,8 +1178,9 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         if (p + 1 < s.p1) {
             // the phase after an even one is a 1x1: its plain g loads need the acquire; a conv phase reads hd
             // with L1-bypassing sc1 LDS-DMA loads and needs none
-            if ((p & 1) == 0) group_barrier<true>(ctr, ++episode * gsize, s.err);
-            else group_barrier<false>(ctr, ++episode * gsize, s.err);
+            // (s.fault: test hook - one arrival more than the group has is awaited, so every wait runs into its bound)
+            if ((p & 1) == 0) group_barrier<true>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
+            else group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
             if (episode == 1) {      // every block of the group has published its XCC id: one L2 for all of them?
                 unsigned mine;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));

@@ -262,6 +262,9 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that
  *                          they are L2-resident when needed.  Performance only (measured: no gain, 888.4 vs 887.2 ms
  *                          per config-2 chain - the loads it would speed up are already hidden).
+ *   "stack_fault_test" [0] test hook: the fused kernel's group barriers await one arrival more than a group has, so
+ *                          every wait runs into its spin bound (~1 s) - the launch ends, flags the time-out, and
+ *                          the next call on the engine fails with DR_EHIP until dr_stack_status clears it.
  *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
  */
 int dr_set_option(dr_engine* e, const char* name, int value);
