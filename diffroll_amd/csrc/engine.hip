@@ -506,14 +506,21 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
-        for (int ni = 1; ni <= 2 && !stack_ni; ++ni) {        // smallest frame tile whose launch is one resident round
-            const long blocks = (long)(Cp / 64) * NB * ((T + 64 * ni - 1) / (64 * ni));
+        // Flavours 1 / 2 (64 / 128-frame blocks) are chosen automatically.  Flavour 5 (160-frame blocks on the 16x16x4
+        // MFMA: what fits BASELINE config 5's 640-frame clips into one resident round) exists and is bit-identical,
+        // but measured 0.5 % SLOWER than the per-phase launches there (1806 vs 1796 ms per chain: 554-us conv phases
+        // gain nothing from losing a 9-us launch, and the merged kernel spills outside its loops) - it only runs when
+        // DR_STACK_FL=5 asks for it (tests / measurements).
+        static const int fl_force = getenv("DR_STACK_FL") ? atoi(getenv("DR_STACK_FL")) : 0;
+        for (int fl : {1, 2, 5}) {          // smallest frame tile whose launch is one resident round
+            if (stack_ni || (fl_force ? fl != fl_force : fl == 5)) continue;
+            const int bn = stack_tile_frames(fl);
+            const long blocks = (long)(Cp / 64) * NB * ((T + bn - 1) / bn);
             // (a launch that fills less than half the chip is better served by the per-phase kernels' split-K;
             // opt_stack == 2 fuses regardless: tests)
             if (blocks <= e->n_cus && blocks <= 1024 && (2 * blocks >= e->n_cus || e->opt_stack == 2) &&
-                NB <= dr_engine::STACK_GROUPS &&
-                gemm_lds_bytes(ni, 1, e->K, maxdil, 0, EPI_GATE) + (size_t)32 * 64 * ni * 16 <= 160 * 1024)
-                stack_ni = ni;
+                NB <= dr_engine::STACK_GROUPS && stack_lds_bytes(fl, e->K, maxdil) <= 160 * 1024)
+                stack_ni = fl;
         }
         const bool dual0 = (bmod > 0 && NB == 2 * bmod && n_cond == bmod);
         if (stack_ni) stack_from = dual0 ? 1 : 0;

@@ -133,8 +133,11 @@ struct StackArgs {
     long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
     StackLayer layer[DR_STACK_MAX_LAYERS];
 };
-// NI in {1, 2}: 64 / 128 frames per block.  The caller guarantees NB * ceil(T / (64 NI)) * (Cp / 64) <= #CUs.
-hipError_t launch_stack(const StackArgs& s, int NI, int max_dil, hipStream_t st);
+// FL = frame-tile flavour: 1 / 2 = 64 / 128 frames per block (32x32x2 MFMA), 5 = 160 frames (16x16x4 MFMA).  The
+// caller guarantees NB * ceil(T / stack_tile_frames(FL)) * (Cp / 64) <= #CUs and stack_lds_bytes(..) <= 160 KiB.
+hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st);
+int stack_tile_frames(int FL);
+size_t stack_lds_bytes(int FL, int taps, int max_dil);
 
 // Per-call scalars of the update that must not be baked into a captured graph: the chain graph reads them from
 // this device block, which a one-thread kernel rewrites (stream-ordered) before every graph launch - a new

@@ -778,9 +778,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
 //   [32 planes][BN] float4) is RESIDENT IN LDS for the whole launch instead of being re-read from and re-written
 //   to global memory by every layer: the epilogue reads and updates it there (no operand registers are held
 //   across the last K steps - with them the fused kernel spilled), only hd goes to global.
-template <int NW, int COH, int RLDS>     // 32-frame MFMA tiles per wave: block = 128 rows x 32*NW frames
-DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int wave, float4* Rs = nullptr) {
-    constexpr int BN = 32 * NW;
+//   TBN / foff (fused kernel, 160-frame tiles): the block's frame tile is TBN frames wide and this call covers its
+//   32*NW frames starting at foff - the 160-frame 1x1 runs as a 96-frame and a 64-frame pass, because one pass
+//   with 5 frame tiles per wave does not fit the fused kernel's register budget without spilling in the K loop.
+template <int NW, int COH, int RLDS, int TBN = 32 * NW>     // 32-frame MFMA tiles per wave: 128 rows x 32*NW frames per call
+DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int wave, float4* Rs = nullptr, const int foff = 0) {
+    constexpr int BN = TBN;
     // X loads are PLAIN also in the fused kernel: the four waves of a block read the same B fragments, and only
     // the CU's L1 turns that into one L2 request instead of four (measured: with L1-bypassing sc1 loads the phase
     // ran 2x slower) - the fused kernel therefore invalidates the L1 once, in the barrier before this phase.
@@ -791,7 +794,7 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
 
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
-    const int t0 = (nt % tps) * BN;
+    const int t0 = (nt % tps) * BN + foff;
     const int NS = a.kchunks;
 
     // Both operands through buffer loads: resource = (this M tile's weight panel | this sample's X tensor) in
@@ -917,7 +920,7 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
             float v[4], bb[4], pv[4], o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[ni][4 * q + e];
-            float4* rs = Rs + (wave * 8 + 2 * q + hi) * BN + ni * 32 + r;    // this quad in the LDS tile (RLDS)
+            float4* rs = Rs + (wave * 8 + 2 * q + hi) * BN + foff + ni * 32 + r;    // this quad in the LDS tile (RLDS)
             f4arr(ebias[q], bb);
             if constexpr (RLDS) f4arr(*rs, pv);
             else f4arr(eop[ni][q], pv);
@@ -1055,7 +1058,12 @@ DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err
     __syncthreads();
 }
 
-template <int NI>
+template <int NJ, int KS, int EPI, int COH>
+DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const int nt);     // defined below
+
+// FL = frame-tile flavour: 1 / 2 = 64 / 128 frames per block on the 32x32x2 MFMA (gemm_body<FL>), 5 = 160 frames on
+// the 16x16x4 MFMA (gemm16_body<5>: 640-frame clips fill the chip's 256 CUs exactly with 4 x 160-frame tiles)
+template <int FL>
 __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The arguments are read through the kernarg segment pointer (constant address space: scalar loads at the
@@ -1066,7 +1074,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
     const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
 #define s (*sp)
-    constexpr int BN = 64 * NI;
+    constexpr int BN = (FL == 5) ? 160 : 64 * FL;
+    constexpr int RWL = (BN + 63) / 64;                    // 64-frame segments of a tile row
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int MT = s.Cp >> 6;
     const int tps = (s.T + BN - 1) / BN;
@@ -1105,12 +1114,13 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         const int lane = threadIdx.x & 63;
-        for (int i = wave; i < 32 * NI; i += 8) {
-            const int pl = i / NI, seg = i - pl * NI;
+        for (int i = wave; i < 32 * RWL; i += 8) {
+            const int pl = i / RWL, seg = i - pl * RWL;
             bool is_res;
             const float* src = tile_plane(pl, is_res);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)s.T * 16u, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0_ + seg * 64 + lane) * 16, 0, 0, 0);
+            if (seg * 64 + lane < BN)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0_ + seg * 64 + lane) * 16, 0, 0, 0);
         }
         // (the first group barrier - or the end of a one-phase launch - drains these loads: s_waitcnt vmcnt(0)
         // + __syncthreads(); a launch that STARTS with a 1x1 phase waits right here)
@@ -1143,7 +1153,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
-            gemm_body<NI, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
+            if constexpr (FL == 5) gemm16_body<5, 1, EPI_GATE, 1>(a, smem, mt, nt);
+            else gemm_body<FL, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
             if (wave >= 4 && s.warm) {
                 // the producers are back while the consumers still contract the last chunk (~16 us at k = 9): warm
                 // the L2 with what comes next - this block's conditioner tile (read by the gate epilogue: 32 planes x
@@ -1167,7 +1178,14 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // tiles have nothing to do
             const bool idle = last && mt < (s.Cp >> 7);
             if (s.dbg && p + 3 == s.p1) a.dbg = s.dbg + 96;       // second-to-last 1x1 phase (block 0 works in it)
-            if (wave < 4 && !idle) pw_body<2 * NI, 1, 1>(a, mt, nt, wave, Rs);
+            if (wave < 4 && !idle) {
+                if constexpr (FL == 5) {
+                    pw_body<3, 1, 1, 160>(a, mt, nt, wave, Rs, 0);
+                    pw_body<2, 1, 1, 160>(a, mt, nt, wave, Rs, 96);
+                } else {
+                    pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
+                }
+            }
             if (wave >= 4 && s.warm && !last) {
                 // idle for the whole 1x1 phase: fetch the first two chunks (2 x taps slabs of 16 KB) of the next
                 // layer's conv weight panel of this M tile
@@ -1198,12 +1216,12 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int lane = threadIdx.x & 63;
-        for (int i = wave; i < 32 * NI; i += 8) {
-            const int pl = i / NI, seg = i - pl * NI;
+        for (int i = wave; i < 32 * RWL; i += 8) {
+            const int pl = i / RWL, seg = i - pl * RWL;
             bool is_res;
             float* dst = tile_plane(pl, is_res);
             const int t = t0_ + seg * 64 + lane;
-            if (t < s.T && (!is_res || s.p1 < 2 * s.L))
+            if (seg * 64 + lane < BN && t < s.T && (!is_res || s.p1 < 2 * s.L))
                 *reinterpret_cast<float4*>(dst + (long)t * 4) = Rs[pl * BN + seg * 64 + lane];
         }
     }
@@ -1219,21 +1237,27 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
 #undef s
 }
 
-hipError_t launch_stack(const StackArgs& s, int NI, int max_dil, hipStream_t st) {
-    if (NI != 1 && NI != 2) return hipErrorInvalidValue;
+hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st) {
+    if (FL != 1 && FL != 2 && FL != 5) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
-    const int BN = 64 * NI, tps = (s.T + BN - 1) / BN, MT = s.Cp >> 6;
-    const size_t xl = gemm_lds_bytes(NI, 1, s.taps, max_dil, 0, EPI_GATE);   // the conv's X tiles ...
-    const size_t lds = xl + (size_t)32 * BN * 16;                            // ... + the resident h / skip tile
+    const int BN = stack_tile_frames(FL), tps = (s.T + BN - 1) / BN, MT = s.Cp >> 6;
+    const size_t lds = stack_lds_bytes(FL, s.taps, max_dil);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     StackArgs b = s;
-    b.rs_off = (int)xl;
+    b.rs_off = (int)(lds - (size_t)32 * BN * 16);
     const int NT = s.NB * tps;
     if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;            // the group-per-XCD mapping deals groups round-robin to 8 XCDs
     const dim3 grid((unsigned)(MT * NT));
-    if (NI == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
-    else hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
+    if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
+    else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
+    else hipLaunchKernelGGL((stack_kernel<5>), grid, dim3(512), lds, st, b);
     return hipGetLastError();
+}
+int stack_tile_frames(int FL) { return FL == 5 ? 160 : 64 * FL; }
+// the conv's double-buffered X tiles + the resident h / skip tile
+size_t stack_lds_bytes(int FL, int taps, int max_dil) {
+    const int BN = stack_tile_frames(FL), halo = ((taps - 1) / 2) * max_dil;
+    return (size_t)2 * 8 * (BN + 2 * halo) * 16 + (size_t)32 * BN * 16;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1245,9 +1269,10 @@ hipError_t launch_stack(const StackArgs& s, int NI, int max_dil, hipStream_t st)
 //   consumers 4 (M) x 1 (N): wave tile = 2 row tiles (paired epilogue: gate 16 / filter 16 of the same
 //   channels) x 2*NJ column tiles = 20 accumulators x 4 registers at NJ = 5.
 // ---------------------------------------------------------------------------------------------
-template <int NJ, int KS, int EPI>
-__global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+//   COH = 1 (fused residual-stack kernel): as gemm_body - X (hd) through sc1 LDS-DMA loads, the gated output
+//   (g) stored write-through unless a.wt_store == 0.
+template <int NJ, int KS, int EPI, int COH>
+DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const int nt) {
     static_assert(EPI == EPI_GATE || EPI == EPI_RES_SKIP, "16x16 variant: hot kernels only");
     constexpr int BN = 32 * NJ;
     constexpr int XP = 8 * KS;
@@ -1264,15 +1289,6 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
     float4* Xs = reinterpret_cast<float4*>(smem);   // [2][XP][FW]
     float4* Rs = Xs + 2 * XP * FW;                  // EPI_RES_SKIP: [32 planes][BN]
 
-    int mt, nt;
-    if (a.xcd_n) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        mt = idx % a.MT;
-        nt = (idx / a.MT) * 8 + xcd;
-    } else {
-        mt = blockIdx.x % a.MT;
-        nt = blockIdx.x / a.MT;
-    }
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
@@ -1296,7 +1312,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;
                 float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
-                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, 0);
+                if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, COH ? 16 : 0);
             }
         };
         if constexpr (EPI == EPI_RES_SKIP) {
@@ -1458,7 +1474,7 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
                     store_s3_quad(a.Y + (long)b * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
                 } else {
                     float* dst = a.Y + (long)b * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
-                    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                    store_f4<COH>(dst, make_float4(o[0], o[1], o[2], o[3]), a.wt_store);
                 }
             }
         } else {
@@ -1497,6 +1513,21 @@ __global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
             }
         }
     }
+}
+
+template <int NJ, int KS, int EPI>
+__global__ __launch_bounds__(512) void gemm16_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int mt, nt;
+    if (a.xcd_n) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        mt = idx % a.MT;
+        nt = (idx / a.MT) * 8 + xcd;
+    } else {
+        mt = blockIdx.x % a.MT;
+        nt = blockIdx.x / a.MT;
+    }
+    gemm16_body<NJ, KS, EPI, 0>(a, smem, mt, nt);
 }
 
 template <int NJ, int KS, int EPI>
@@ -1605,6 +1636,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return init_gemm16();
 }
 

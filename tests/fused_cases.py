@@ -33,6 +33,11 @@ CASES = {
         (512, 2, 15, 16, 200, "generation_ddpm_x0"),
         (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
     ],
+    5: [  # 160-frame blocks on the 16x16x4 MFMA (DR_STACK_FL=5: measured slower than per-phase launches, kept tested)
+        (512, 2, 15, 4, 640, "cfdg_ddpm_x0"),       # BASELINE config 5 per-GPU geometry: 8 evaluations x 4 tiles x 8 M tiles
+        (512, 2, 9, 6, 300, "generation_ddpm_x0"),  # ragged second tile, 1x1 as a 96- and a 64-frame pass
+        (192, 3, 9, 3, 161, "ddpm_x0"),             # one frame in the second tile; M tile straddling the halves
+    ],
 }
 
 

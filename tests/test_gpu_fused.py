@@ -34,13 +34,15 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", [1, 2])
+@pytest.mark.parametrize("ni", [1, 2, 5])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one frame-tile width, in a child process whose per-phase kernels are
     pinned to the flavours the fused kernel is built from (the overrides are read once per process)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni))
+    if ni == 5:      # the 160-frame flavour: 16x16 MFMA conv tiles, 1x1 with 5 frame tiles per wave; only on request
+        env.update(DR_TILE="16:5", DR_PW_NW="5", DR_STACK_FL="5")
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
