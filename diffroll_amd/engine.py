@@ -40,8 +40,11 @@ class Engine:
                  beta_start: float, beta_end: float, sample_rate: int = 16000, n_fft: int = 2048,
                  hop_length: int = 512, f_min: float = 0.0, f_max: float = 8000.0,
                  device: Optional[torch.device] = None, betas: Optional[torch.Tensor] = None,
-                 norm_mode: str = "imagewise"):
-        """betas: optional (timesteps,) schedule replacing linspace(beta_start, beta_end) (diffroll_amd.schedule)."""
+                 norm_mode: str = "imagewise", fe_window: Optional[torch.Tensor] = None,
+                 fe_fb: Optional[torch.Tensor] = None):
+        """betas: optional (timesteps,) schedule replacing linspace(beta_start, beta_end) (diffroll_amd.schedule).
+        fe_window (n_fft,) / fe_fb (n_fft//2+1, n_mels): the MelSpectrogram buffers of a checkpoint, used instead of
+        the tables diffroll_amd.frontend_tables evaluates (which are the same expressions)."""
         if not torch.cuda.is_available():
             raise EngineError("no ROCm device visible: diffroll_amd runs only on an MI355X (no CPU fallback)")
         self.lib = _cabi.load_library()
@@ -74,7 +77,15 @@ class Engine:
             C.cast(self._tables[1].data_ptr(), C.POINTER(C.c_float))))
         # front-end constants with the reference's fp32 arithmetic (torch.hann_window, torchaudio's melscale_fbanks)
         from .frontend_tables import frontend_tables
-        self._fe_tables = frontend_tables(n_fft, f_min, f_max, n_mels, sample_rate)
+        w, wn, fb = frontend_tables(n_fft, f_min, f_max, n_mels, sample_rate)
+        if fe_window is not None:
+            w = fe_window.detach().to("cpu", torch.float32).contiguous()
+            wn = float(w.pow(2.0).sum().sqrt())
+        if fe_fb is not None:
+            fb = fe_fb.detach().to("cpu", torch.float32).contiguous()
+        if tuple(w.shape) != (n_fft,) or tuple(fb.shape) != (n_fft // 2 + 1, n_mels):
+            raise ValueError(f"front-end tables of shape {tuple(w.shape)} / {tuple(fb.shape)} do not fit n_fft={n_fft}, n_mels={n_mels}")
+        self._fe_tables = (w, wn, fb)
         self._check(self.lib.dr_set_frontend_tables(
             self.h, C.cast(self._fe_tables[0].data_ptr(), C.POINTER(C.c_float)), C.c_float(self._fe_tables[1]),
             C.cast(self._fe_tables[2].data_ptr(), C.POINTER(C.c_float))))

@@ -209,6 +209,7 @@ class ClassifierFreeDiffRoll(nn.Module):
     def engine(self) -> Engine:
         if self._engine is None:
             self._engine = Engine(device=self._device, betas=self._betas(), norm_mode=str(self.hparams.norm_args[2]),
+                                  fe_window=self.__dict__.get("_ckpt_window"), fe_fb=self.__dict__.get("_ckpt_fb"),
                                   **self._engine_kwargs)
             self._dirty = True
         if self._dirty:
@@ -232,6 +233,20 @@ class ClassifierFreeDiffRoll(nn.Module):
         own = {k: v for k, v in state_dict.items()
                if not k.startswith("mel_layer.") and k != "diffusion_embedding.embedding"}
         out = super().load_state_dict(own, strict=strict)
+        # the MelSpectrogram buffers of a reference checkpoint (torchaudio 0.11 names) are the front-end tables
+        # themselves: use them (they equal diffroll_amd.frontend_tables' output, which is what runs without them)
+        win, fb = state_dict.get("mel_layer.spectrogram.window"), state_dict.get("mel_layer.mel_scale.fb")
+        n_fft, n_mels = self._engine_kwargs["n_fft"], self._engine_kwargs["n_mels"]
+        changed = False
+        if win is not None and tuple(win.shape) == (n_fft,):
+            self.__dict__["_ckpt_window"] = win.detach().float().cpu()
+            changed = True
+        if fb is not None and tuple(fb.shape) == (n_fft // 2 + 1, n_mels):
+            self.__dict__["_ckpt_fb"] = fb.detach().float().cpu()
+            changed = True
+        if changed and self._engine is not None:          # tables are fixed at engine creation: rebuild lazily
+            self._engine.close()
+            self._engine = None
         self._dirty = True
         return out
 
