@@ -212,6 +212,9 @@ def main():
                     help="BASELINE.json config (1-based) at its per-GPU shape; default 2 = the headline workload")
     ap.add_argument("--dist", action="store_true",
                     help="plain single-process run: still create a 1-rank RCCL group (exercises init / all-gather / barrier)")
+    ap.add_argument("--gather-check", action="store_true",
+                    help="multi-rank runs: also create a C-ABI communicator (dr_comm_create) and compare dr_gather with "
+                         "torch's all-gather (always done in 1-rank groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
@@ -347,7 +350,9 @@ def main():
                 "thresholded_frames_differing": int(((out3 > 0.5) != (out > 0.5)).sum()),
                 "note": "opt-in precision mode; identical inputs and Philox noise as the headline run",
             }
-    if dist is not None:
+    if dist is not None and (args.gather_check or world == 1):
+        # (multi-rank runs: only with --gather-check - a second communicator is created collectively, and the headline
+        # measurement must never depend on it)
         # the same collective through the C-ABI (dr_comm_create / dr_gather: RCCL via dlopen, no torch.distributed in
         # the data path) - run once next to the timed region and compared with torch's all-gather; reported, never
         # allowed to fail the measurement

@@ -439,8 +439,10 @@ def test_load_from_checkpoint_end_to_end(tmp_path):
     hp.update(residual_channels=64, residual_layers=3, kernel_size=9, timesteps=6)
     p = R.synthetic_params(hp, seed=77)
     sd = dict(p)
-    sd["mel_layer.spectrogram.window"] = torch.hann_window(2048)
-    sd["mel_layer.mel_scale.fb"] = torch.zeros(1025, 229)
+    # the MelSpectrogram buffers a real checkpoint carries ARE used as the front-end tables (as load_state_dict would
+    # load them into mel_layer in the reference): here torchaudio's own values
+    from diffroll_amd.frontend_tables import frontend_tables
+    sd["mel_layer.spectrogram.window"], _, sd["mel_layer.mel_scale.fb"] = frontend_tables(2048, 0.0, 8000.0, 229, 16000)
     hyper = dict(residual_channels=64, unconditional=False, condition="fixed", n_mels=229, norm_args=[0, 1, "imagewise"],
                  residual_layers=3, kernel_size=3, dilation_base=2, dilation_bound=4, spec_dropout=0.1,
                  spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000, center=True,
@@ -460,6 +462,13 @@ def test_load_from_checkpoint_end_to_end(tmp_path):
     a, _ = m.sample(x, wav, noise=nz)
     b, _ = ref.sample(x, wav, noise=nz)
     assert torch.equal(a, b)
+    # ... and a checkpoint whose filterbank buffer differs (here: scaled) changes the spectrogram accordingly
+    sd2 = dict(sd)
+    sd2["mel_layer.mel_scale.fb"] = 4.0 * sd["mel_layer.mel_scale.fb"]
+    m.load_state_dict(sd2, strict=False)
+    _, spec_scaled = m(x, wav, torch.tensor([3, 3]))
+    _, spec_ref = ref(x, wav, torch.tensor([3, 3]))
+    assert float((spec_scaled - spec_ref).abs().max()) > 1e-3      # log(4 m + 1e-6) is not a pure shift of log(m + 1e-6)
 
 
 def test_cli_drivers_end_to_end(tmp_path):
