@@ -79,6 +79,41 @@ def main():
         rec["vs_oracle"] = float((ref.cpu() - want).abs().max())
         out.append(rec)
         del m
+    if ni == 1:
+        # the remaining conditioner variants of the gate epilogue inside the fused kernel: the learned unconditional
+        # spectrogram of condition='trainable_spec' (cond2, model/diffwave.py:656-658) and the spec == 0 branch of
+        # cfdg_ddim_x0 (task/diffusion.py:1027-1055)
+        from diffroll_amd import ClassifierFreeDiffRoll
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=128, residual_layers=3, kernel_size=9, timesteps=6)
+        p = R.synthetic_params(hp, seed=9)
+        for label, cond, sampler in (("trainable_spec", "trainable_spec", "cfdg_ddpm_x0"), ("zero_spec", "fixed", "cfdg_ddim_x0")):
+            m = ClassifierFreeDiffRoll(
+                residual_channels=128, unconditional=False, condition=cond, n_mels=229, norm_args=[0, 1, "imagewise"],
+                residual_layers=3, kernel_size=9, dilation_base=2, dilation_bound=4,
+                spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000,
+                               center=True, normalized=True, pad_mode="reflect"),
+                timesteps=6, training={"mode": "x_0"}, sampling={"type": sampler, "w": 0.5})
+            sd = dict(p)
+            if cond == "trainable_spec":
+                sd["trainable_parameters"] = torch.rand(229, 641, generator=torch.Generator().manual_seed(2)) * 2 - 1
+            m.load_state_dict(sd)
+            g = torch.Generator().manual_seed(31)
+            B, Tn = 4, 100
+            wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+            x = torch.randn(B, 1, Tn, 88, generator=g)
+            z = torch.randn(B, 1, Tn, 88, generator=g)
+            eng = m.engine
+            eng.set_option("fused_stack", 0)
+            ref = m.reverse_diffusion(x, wav, 3, noise=z)[0]
+            eng.set_option("fused_stack", 2)
+            eng.stack_status()
+            n0 = eng.stack_launches
+            got = m.reverse_diffusion(x, wav, 3, noise=z)[0]
+            flag, _ = eng.stack_status()
+            out.append({"case": [label], "vs_oracle": 0.0,
+                        "runs": [{"xcd": 1, "timed_out": flag, "launches": eng.stack_launches - n0, "kernel": "stack_kernel<1>",
+                                  "equal": bool(torch.equal(got, ref)), "maxdiff": float((got - ref).abs().max())}]})
     print("FUSED_CASES " + json.dumps(out), flush=True)
 
 

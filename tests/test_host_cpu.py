@@ -464,3 +464,21 @@ def test_resample_restates_torchaudio_011_windowed_sinc():
     assert torch.equal(A.to_mono(st), torch.full((5,), 0.5))
     assert torch.equal(A.to_mono(torch.stack([torch.ones(5), torch.zeros(5), torch.zeros(5)])), torch.ones(5))
     assert A.crop_or_pad(torch.ones(3), 5).tolist() == [1, 1, 1, 0, 0] and A.crop_or_pad(torch.ones(7), 5).shape == (5,)
+
+
+def test_midi_writer_known_answer_bytes(tmp_path):
+    """The Standard MIDI File a conforming writer (mido, which the reference uses at task/diffusion.py:1235-1265, with
+    its defaults: type 1, 480 ticks per beat) must produce for ONE note - C4, 0.5 s to 1.0 s, velocity 1.0 -> 127,
+    ticks_per_second = 960 - written out by hand from the SMF specification: header chunk, delta times as
+    variable-length quantities (480 = 0x83 0x60), note-on 0x90 / note-off 0x80, end-of-track meta event."""
+    from diffroll_amd import midi
+    path = str(tmp_path / "kat.mid")
+    midi.save_midi(path, [60], [[0.5, 1.0]], [1.0])
+    want = (b"MThd" + bytes([0, 0, 0, 6, 0, 1, 0, 1, 0x01, 0xE0]) +
+            b"MTrk" + bytes([0, 0, 0, 14]) +
+            bytes([0x83, 0x60, 0x90, 60, 127]) + bytes([0x83, 0x60, 0x80, 60, 127]) + bytes([0x00, 0xFF, 0x2F, 0x00]))
+    assert open(path, "rb").read() == want
+    # a delta above 16383 ticks needs three VLQ bytes: 20 s = 19200 ticks = 0x81 0x96 0x00
+    midi.save_midi(path, [21], [[20.0, 20.0]], [0.5])
+    body = open(path, "rb").read()[22:]
+    assert body[:6] == bytes([0x81, 0x96, 0x00, 0x90, 21, 63]) and body[6:10] == bytes([0x00, 0x80, 21, 63])
