@@ -41,6 +41,11 @@ def gather_rolls(local: torch.Tensor, group=None, comm: Optional["NativeComm"] =
         return local
     ws = d.get_world_size(group)
     local = local.contiguous()
+    if local.is_cuda and d.get_backend(group) == "gloo":
+        # a gloo group (CPU-only rendezvous, or several ranks sharing one GPU in tests): gather host copies
+        parts = [torch.empty(local.shape, dtype=local.dtype) for _ in range(ws)]
+        d.all_gather(parts, local.cpu(), group=group)
+        return torch.cat(parts, 0).to(local.device)
     out = torch.empty((ws * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     d.all_gather_into_tensor(out, local, group=group)
     return out

@@ -159,3 +159,66 @@ def test_native_comm_one_rank_gather_through_the_cabi():
     z = comm.all_gather(x[:, 0].contiguous())
     assert torch.equal(z, x[:, 0])
     comm.close()
+
+
+_TWO_RANK_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch
+import torch.distributed as dist
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = sys.argv[3]
+torch.cuda.set_device(0)                     # both ranks on the one leased GPU
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from test_gpu_sharding import _model
+from diffroll_amd.distributed import sample_sharded, world as wfn
+assert wfn() == (rank, world)
+hp, p, m = _model(layers=3, steps=8, C=512)       # full width: the fused residual-stack kernel is the one that runs
+torch.manual_seed(5)
+B, Tn = 12, 125
+wav = 0.1 * torch.randn(B, Tn * 512)
+x = torch.randn(B, 1, Tn, 88)
+out = []
+for rep in range(3):
+    full = sample_sharded(m, x, wav, seed=3 + rep)
+    out.append(full.cpu())
+flag, _ = m.engine.stack_status()
+dist.barrier()
+if rank == 0:
+    torch.save(out, sys.argv[4])
+print("RANK_DONE", rank, flag, m.engine.stack_launches)
+dist.destroy_process_group()
+"""
+
+
+def test_two_processes_share_the_gpu_and_gather(tmp_path):
+    """A real 2-process job on the ONE leased GPU (gloo rendezvous, host-side gather): each rank runs its 6-clip shard
+    through its own engine - two processes' fused kernels time-share the chip - and every rank returns the full
+    batch, equal to the unsharded result of a single process.  (The RCCL flavour of the same job needs two GPUs.)"""
+    from diffroll_amd.distributed import sample_sharded
+    from diffroll_amd.launch import free_port
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    port = str(free_port())
+    res = str(tmp_path / "full.pt")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK_SCRIPT.format(root=ROOT), str(r), "2", port, res], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "RANK_DONE" in so, (so[-1500:], se[-3000:])
+        done = [ln for ln in so.splitlines() if ln.startswith("RANK_DONE")][-1].split()
+        assert done[2] == "0", so                       # no barrier time-out in either process
+        assert int(done[3]) > 0, so                     # and the fused kernel is what ran (192 blocks per process)
+    got = torch.load(res)
+    hp, p, m = _model(layers=3, steps=8, C=512)
+    torch.manual_seed(5)
+    B, Tn = 12, 125
+    wav = 0.1 * torch.randn(B, Tn * 512)
+    x = torch.randn(B, 1, Tn, 88)
+    for rep in range(3):
+        whole = sample_sharded(m, x, wav, seed=3 + rep).cpu()
+        d = float((got[rep] - whole).abs().max())
+        assert d <= ATOL_SHARD, (rep, d)
