@@ -1011,9 +1011,9 @@ hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s) {
 //
 // Hand-off form (MI355X_MICROARCH.md "inter-workgroup visibility", valid under any block -> XCD placement):
 // producers store g / hd write-through (sc1) -> every wave drains (s_waitcnt vmcnt(0)) -> __syncthreads() ->
-// one lane arrives on the group counter (relaxed, agent scope) and polls it -> [one agent-scope acquire when the
-// next phase reads with plain loads] -> __syncthreads() -> consumers read hd with sc1 LDS-DMA loads (L1 bypassed)
-// and g with plain loads (L1 freshly invalidated); the XCD's L2 is never left with a stale copy: a write-through
+// one lane arrives on the group counter (relaxed, agent scope) and polls it -> __syncthreads() -> consumers read hd
+// with sc1 LDS-DMA loads (L1 bypassed) and g with plain loads - through an L1 that a producer wave invalidated
+// (agent-scope acquire) during the preceding conv phase, after the CU's last read of the previous g; the XCD's L2 is never left with a stale copy: a write-through
 // store drops / invalidates it.  Counters are re-armed by the last block of the group to leave the launch, so a
 // replayed graph needs no memset node.  Spins are bounded: a wait that runs into the bound sets *err and
 // carries on (wrong data, but no hung queue).
@@ -1155,6 +1155,14 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
             if constexpr (FL == 5) gemm16_body<5, 1, EPI_GATE, 1>(a, smem, mt, nt);
             else gemm_body<FL, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
+            // The agent-scope acquire the NEXT phase needs (the 1x1 reads g, written by other workgroups, with plain
+            // loads through this CU's L1): one producer wave issues it here, while the consumers still contract the
+            // last chunk, instead of everyone waiting ~1.7 us for it behind the barrier.  It is valid anywhere
+            // between the previous 1x1 phase's last g load and the next one's first: no wave of this CU reads a g
+            // address in a conv phase (weights and the conditioner are read-only, hd comes through L1-bypassing sc1
+            // LDS-DMA), so no g line can re-enter the L1 after this invalidate; the conv's own weight-fragment loads
+            // are used once each and lose nothing.
+            if (wave == 4) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (wave >= 4 && s.warm) {
                 // the producers are back while the consumers still contract the last chunk (~16 us at k = 9): warm
                 // the L2 with what comes next - this block's conditioner tile (read by the gate epilogue: 32 planes x
@@ -1194,11 +1202,10 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             }
         }
         if (p + 1 < s.p1) {
-            // the phase after an even one is a 1x1: its plain g loads need the acquire; a conv phase reads hd
-            // with L1-bypassing sc1 LDS-DMA loads and needs none
+            // (no acquire here: a conv phase reads hd with L1-bypassing sc1 LDS-DMA loads, and the 1x1 phase's L1
+            // invalidate was issued by a producer wave during the conv phase, above)
             // (s.fault: test hook - one arrival more than the group has is awaited, so every wait runs into its bound)
-            if ((p & 1) == 0) group_barrier<true>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
-            else group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
+            group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
             if (episode == 1) {      // every block of the group has published its XCC id: one L2 for all of them?
                 unsigned mine;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));

@@ -260,8 +260,9 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
  *                          0 = one weight panel per XCD.  Performance only.
  *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that
- *                          they are L2-resident when needed.  Performance only (measured: no gain, 888.4 vs 887.2 ms
- *                          per config-2 chain - the loads it would speed up are already hidden).
+ *                          they are L2-resident when needed.  Performance only (measured: 888.6 vs 889.3 ms per
+ *                          config-2 chain, i.e. nothing, and 511.6 vs 486.3 ms at config 3 - the loads it would
+ *                          speed up are already hidden, and with 64-frame blocks the extra traffic hurts).
  *   "stack_fault_test" [0] test hook: the fused kernel's group barriers await one arrival more than a group has, so
  *                          every wait runs into its spin bound (~1 s) - the launch ends, flags the time-out, and
  *                          the next call on the engine fails with DR_EHIP until dr_stack_status clears it.

@@ -108,15 +108,20 @@ def test_fused_stack_soak_under_uneven_load():
     eng.set_option("fused_stack", 2)
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, device="cuda")
-    for it in range(40):
-        if it % 2:
-            with torch.cuda.stream(side):
-                for _ in range(4):
-                    big.copy_(big.flip(0))
-        out = m.reverse_diffusion(x, wav, 2, noise=z)[0]
-        assert torch.equal(out, ref), it
-    torch.cuda.synchronize()
-    assert eng.stack_status()[0] == 0
+    # mapping 1: every group inside one XCD (plain stores, shared L2); mapping 0: groups span all XCDs, so every
+    # hand-off is write-through stores + loads that must not hit a stale line in ANOTHER XCD's L2
+    for xcd in (1, 0):
+        eng.set_option("fused_stack_xcd", xcd)
+        for it in range(40):
+            if it % 2:
+                with torch.cuda.stream(side):
+                    for _ in range(4):
+                        big.copy_(big.flip(0))
+            out = m.reverse_diffusion(x, wav, 2, noise=z)[0]
+            assert torch.equal(out, ref), (xcd, it)
+        torch.cuda.synchronize()
+        assert eng.stack_status()[0] == 0
+    eng.set_option("fused_stack_xcd", 1)
     eng.set_option("fused_stack", 1)
 
 
