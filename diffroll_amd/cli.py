@@ -140,8 +140,9 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
     if gpus > 1 and not launch.under_launcher():
         # `gpus=N` is the reference's one flag for N devices (Trainer(gpus=cfg.gpus), sampling.py:70): start the
         # N ranks here, one process per GPU
-        script = os.path.abspath(sys.argv[0]) if argv is None else os.path.abspath(sys.modules["__main__"].__file__)
-        raise SystemExit(launch.spawn_ranks(gpus, script, list(sys.argv[1:] if argv is None else argv)))
+        if argv is not None:      # called as a function: there is no command line to re-execute
+            raise SystemExit(f"gpus={gpus}: start the {gpus} ranks with torch.distributed.run (or run the driver script)")
+        raise SystemExit(launch.spawn_ranks(gpus, os.path.abspath(sys.argv[0]), list(sys.argv[1:])))
     rank, world, local_rank = launch.rank_env()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)

@@ -920,7 +920,8 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
             float v[4], bb[4], pv[4], o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[ni][4 * q + e];
-            float4* rs = Rs + (wave * 8 + 2 * q + hi) * BN + foff + ni * 32 + r;    // this quad in the LDS tile (RLDS)
+            float4* rs = nullptr;                                                   // this quad in the LDS tile (RLDS)
+            if constexpr (RLDS) rs = Rs + (wave * 8 + 2 * q + hi) * BN + foff + ni * 32 + r;
             f4arr(ebias[q], bb);
             if constexpr (RLDS) f4arr(*rs, pv);
             else f4arr(eop[ni][q], pv);
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     (void)s_by_value;
     typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
     const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
-#define s (*sp)
+    const __attribute__((address_space(4))) StackArgs& s = *sp;
     constexpr int BN = (FL == 5) ? 160 : 64 * FL;
     constexpr int RWL = (BN + 63) / 64;                    // 64-frame segments of a tile row
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1241,7 +1242,6 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-#undef s
 }
 
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st) {
