@@ -14,6 +14,9 @@ PS="python $R/tools/prof_summary.py"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_kt.log" 2>&1
 echo "kernel trace rc=$?"
 $PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split (MI355X, config 2; stack_kernel<NI> = fused residual stack: 14 dilated convs + 15 1x1 per launch; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log; the gemm_kernel<..,3,..> rows here are layer 0's conv + the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline > "$OUT/bench_kt1.log" 2>&1
+$PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
+rm -rf "$OUT/kt1"
 for cfg in 2 3; do
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
 echo "fetch cfg$cfg rc=$?"
