@@ -75,10 +75,13 @@ def main():
         nz = [t for t in ticks[:-1] if t]
         if len(nz) > 1:
             d = [b - a for a, b in zip(nz[:-1], nz[1:])]
-            conv = [v for i, v in enumerate(d) if (len(d) - i) % 2 == 0]
-            pw = [v for i, v in enumerate(d) if (len(d) - i) % 2 == 1]
-            print(f"xcd={xcd}: phase ticks: conv mean {sum(conv) / max(len(conv), 1):.0f}, 1x1 mean {sum(pw) / max(len(pw), 1):.0f}, "
-                  f"total {nz[-1] - nz[0]}; per phase {d}", flush=True)
+            tail, d = d[-1], d[:-1]                 # the last mark pair brackets the write-back of the resident tile
+            cut = 2 * min(d)                        # conv phases are ~8x the 1x1 phases
+            conv = [v for v in d if v > cut]
+            pw = [v for v in d[1:] if v <= cut]     # (the first phase also waits for the resident tile's load)
+            print(f"xcd={xcd}: phase ticks (shader cycles, block 0, barrier waits included): {len(conv)} conv phases mean "
+                  f"{sum(conv) / max(len(conv), 1):.0f}, {len(pw)} 1x1 phases mean {sum(pw) / max(len(pw), 1):.0f} (first phase {d[0]}), "
+                  f"tail {tail}, total {nz[-1] - nz[0]}; per phase {d}", flush=True)
         eng.set_option("stack_ticks", 0)
 
     def chain_ms(n=2):
