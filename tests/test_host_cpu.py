@@ -482,3 +482,23 @@ def test_midi_writer_known_answer_bytes(tmp_path):
     midi.save_midi(path, [21], [[20.0, 20.0]], [0.5])
     body = open(path, "rb").read()[22:]
     assert body[:6] == bytes([0x81, 0x96, 0x00, 0x90, 21, 63]) and body[6:10] == bytes([0x00, 0x80, 21, 63])
+
+
+def test_bench_workloads_match_the_survey_figures():
+    """bench.py's per-config algorithmic FLOPs / bytes are SURVEY.md 8(d)'s: chain FLOPs 1.97 / 126.4 / 63.2 / 126.4 /
+    258.4 T per GPU and chain bytes 33.6 / 252 / 114 / 252 / 363 GB - the figures `whole_chain` and `hbm_roofline`
+    divide by the measured time."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.flops_per_frame_eval(9) == 157990912 and bench.flops_per_frame_eval(15) == 252362752
+    want_tflop = {1: 1.97, 2: 126.4, 3: 63.2, 4: 126.4, 5: 258.4}
+    want_gb = {1: 33.6, 2: 252.0, 3: 114.0, 4: 252.0, 5: 363.0}
+    for c, cfg in bench.CONFIGS.items():
+        T = cfg["L"] // 512
+        fl = bench.flops_per_frame_eval(cfg["k"]) * cfg["B"] * T * cfg["evals"] * cfg["S"]
+        assert abs(fl / 1e12 - want_tflop[c]) / want_tflop[c] < 5e-3, (c, fl)
+        assert abs(bench.chain_bytes(cfg, T) / 1e9 - want_gb[c]) / want_gb[c] < 1e-2, (c, bench.chain_bytes(cfg, T))
+    assert len(bench.csrc_digest()) == 16
