@@ -26,7 +26,10 @@ def counters(d):
 def main():
     fetch_dir, write_dir, config, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     cf, cw = counters(fetch_dir), counters(write_dir)
-    kern = max((k for k in cf if "stack_kernel" in k or "gemm_kernel<2, 1, 3, 0>" in k or "gemm_kernel<1, 1, 3, 0>" in k),
+    # the dominant kernel of the run: the fused stack where it is used, else the conv + gate kernel (EPI 3) of either
+    # MFMA flavour
+    import re
+    kern = max((k for k in cf if "stack_kernel" in k or re.search(r"gemm_kernel<\d, 1, 3, 0>|gemm16_kernel<\d, 1, 3>", k)),
                key=lambda k: sum(cf[k]["FETCH_SIZE"]))
     mean = lambda v: sum(v) / len(v)      # noqa: E731
     fetch_kb = mean(cf[kern]["FETCH_SIZE"])
@@ -49,7 +52,7 @@ def main():
         algo = n_conv * (conv_w + conv_a) + Lr * (pw_w + pw_a)
         tag = "stack"
     else:
-        algo = conv_w + conv_a
+        algo = conv_w + conv_a          # (launches of layer 0 under guidance contract half the samples: a lower bound there)
         tag = "conv_gate"
     rec = {
         "kernel": kern[:160], "kernel_tag": f"{tag}:config{config}", "csrc_digest": bench.csrc_digest(),

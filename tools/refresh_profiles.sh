@@ -17,12 +17,12 @@ $PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline > "$OUT/bench_kt1.log" 2>&1
 $PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
 rm -rf "$OUT/kt1"
-for cfg in 2 3; do
+for cfg in 1 2 3 4 5; do
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
 echo "fetch cfg$cfg rc=$?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pw$cfg" -o pw -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pw$cfg.log" 2>&1
 echo "write cfg$cfg rc=$?"
-python "$R/tools/make_traffic_json.py" "$OUT/pf$cfg" "$OUT/pw$cfg" $cfg "$OUT/${RD}_stack_cfg${cfg}_traffic.json"
+python "$R/tools/make_traffic_json.py" "$OUT/pf$cfg" "$OUT/pw$cfg" $cfg "$OUT/${RD}_dominant_cfg${cfg}_traffic.json"
 done
 $PS "$OUT/pf2" pf "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_fetch.txt"
 $PS "$OUT/pw2" pw "rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_write.txt"
@@ -33,15 +33,15 @@ timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_
 echo "lds rc=$?"
 $PS "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_lds.txt"
 cd "$R"
-mkdir -p profiles_tmp && cp "$OUT"/${RD}_stack_cfg*_traffic.json profiles/ 2>/dev/null   # so that bench.py finds the stamped record
+mkdir -p profiles_tmp && cp "$OUT"/${RD}_dominant_cfg*_traffic.json profiles/ 2>/dev/null   # so that bench.py finds the stamped record
 for c in 1 2 3 4 5; do
   extra="--no-split --no-cpu-baseline"; [ $c = 2 ] && extra=""
   timeout 900 python bench.py --config $c $extra > "$OUT/${RD}_bench_cfg$c.json" 2> "$OUT/bench_cfg$c.err"; echo "bench cfg$c rc=$?"
 done
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
-rm -rf "$OUT/kt" "$OUT/pf2" "$OUT/pw2" "$OUT/pf3" "$OUT/pw3" "$OUT/pm" "$OUT/pl" profiles_tmp
+rm -rf "$OUT/kt" "$OUT"/pf[1-5] "$OUT"/pw[1-5] "$OUT/pm" "$OUT/pl" profiles_tmp
 head -14 "$OUT/${RD}_kernel_stats.txt"
-cat "$OUT"/${RD}_stack_cfg*_traffic.json
+cat "$OUT"/${RD}_dominant_cfg*_traffic.json
 grep -A8 "stack_kernel" "$OUT/${RD}_stack_pmc_mfma.txt" | head -12
 for c in 1 2 3 4 5; do python - "$OUT/${RD}_bench_cfg$c.json" <<'PY'
 import json,sys
