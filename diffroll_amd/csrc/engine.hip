@@ -502,7 +502,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     // (exact fp32 only; the first layer's conv stays a launch of its own under classifier-free guidance, where it
     // is contracted once per (conditional, unconditional) pair)
     int stack_from = -1;                   // first phase run by the fused kernel (-1: none)
-    int stack_ni = 0;
+    int stack_ni = 0, stack_chunks = 1;    // flavour, and how many sample chunks the evaluation is launched in
     if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
@@ -512,56 +512,91 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         // gain nothing from losing a 9-us launch, and the merged kernel spills outside its loops) - it only runs when
         // DR_STACK_FL=5 asks for it (tests / measurements).
         static const int fl_force = getenv("DR_STACK_FL") ? atoi(getenv("DR_STACK_FL")) : 0;
-        for (int fl : {1, 2, 5}) {          // smallest frame tile whose launch is one resident round
-            if (stack_ni || (fl_force ? fl != fl_force : fl == 5)) continue;
+        // A launch must be ONE resident round (groups spin on each other), so an evaluation with more samples than
+        // fit is launched in balanced CHUNKS of samples, one fused launch after the other (samples are independent).
+        // Cost model per frame-tile width, as pick_tile's: (block rounds over the CUs) x (frames per block) x a
+        // per-width penalty (64-frame blocks load twice the weight fragments per MFMA; 16x16 tiles more operands) -
+        // for the fused kernel rounds = chunks, minus what fusing was measured to save; fused wins if its best width
+        // costs no more than the per-phase launches' best width.
+        const int MT = Cp / 64;
+        auto per_phase_cost = [&]() {
+            double best = 1e30;
+            const struct { int bn; double pen; } cands[] = {{64, 1.0 / 0.93}, {96, 1.04}, {128, 1.0}, {160, 1.04}};
+            for (const auto& c : cands) {
+                const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
+                best = std::min(best, (double)((blocks + e->n_cus - 1) / e->n_cus) * c.bn * c.pen);
+            }
+            return best;
+        };
+        double best = 1e30;
+        for (int fl : {1, 2, 5}) {
+            if (fl_force ? fl != fl_force : fl == 5) continue;
             const int bn = stack_tile_frames(fl);
-            const long blocks = (long)(Cp / 64) * NB * ((T + bn - 1) / bn);
-            // (a launch that fills less than half the chip is better served by the per-phase kernels' split-K;
-            // opt_stack == 2 fuses regardless: tests)
-            if (blocks <= e->n_cus && blocks <= 1024 && (2 * blocks >= e->n_cus || e->opt_stack == 2) &&
-                NB <= dr_engine::STACK_GROUPS && stack_lds_bytes(fl, e->K, maxdil) <= 160 * 1024)
-                stack_ni = fl;
+            const long gsize = (long)MT * ((T + bn - 1) / bn);                          // blocks per sample
+            const long cap = std::min<long>(e->n_cus, 1024) / gsize;                    // samples per launch
+            if (cap < 1 || stack_lds_bytes(fl, e->K, maxdil) > 160 * 1024) continue;
+            const long chunks = (NB + cap - 1) / cap;
+            if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
+            // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
+            // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
+            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : (fl == 5 ? 1.04 : 1.0));
+            // (a single launch that fills less than half the chip is better served by the per-phase kernels'
+            // split-K, which this cost model does not see; opt_stack == 2 fuses regardless: tests)
+            const bool ok = e->opt_stack == 2 || (chunks == 1 ? 2 * NB * gsize >= e->n_cus : true);
+            if (ok && cost < best) { best = cost; stack_ni = fl; stack_chunks = (int)chunks; }
         }
+        if (stack_ni && e->opt_stack != 2 && best > per_phase_cost()) stack_ni = 0;
         const bool dual0 = (bmod > 0 && NB == 2 * bmod && n_cond == bmod);
         if (stack_ni) stack_from = dual0 ? 1 : 0;
     }
     auto launch_stack_range = [&](int p0, int p1) -> int {
-        StackArgs sa{};
-        sa.h = e->h; sa.hd = e->hd; sa.g = e->g; sa.skip = e->skip;
-        sa.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
-        sa.tsel = tsel; sa.d2_ts = (long)L * Cp;
-        sa.zero = zero_vec();
-        sa.NB = NB; sa.T = T; sa.Cp = Cp; sa.taps = e->K; sa.n_cond = n_cond; sa.L = L;
-        sa.c_bs = (long)2 * Cp * T;
-        sa.p0 = p0; sa.p1 = p1;
-        sa.xcd_n = e->opt_stack_xcd;
-        sa.warm = e->opt_stack_warm;
-        sa.fault = e->opt_stack_fault;
-        sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
-        sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
         int maxdil = 1;
-        for (int l = 0; l < L; ++l) {
-            const LayerW& w = e->layers[l];
-            StackLayer& y = sa.layer[l];
-            y.conv_w = w.conv_w; y.conv_b = w.conv_b;
-            y.conv_b2 = zero_spec ? w.conv_b_z : w.conv_b_u;
-            y.cond2 = nullptr;
-            if (e->cond_tr && !zero_spec) { y.cond2 = e->cond_tr + (size_t)l * 2 * Cp * T; y.conv_b2 = w.conv_b; }
-            y.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
-            y.out_w = w.out_w; y.out_b = w.out_b; y.dil = w.dil;
-            maxdil = std::max(maxdil, w.dil);
-        }
-        const bool timed = e->prof && e->prof_used < e->prof_events.size();
-        if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-        HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
-        e->stack_launches += 1;
-        if (timed) {
-            HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
-            const double C = e->C, fr = (double)NB * T;
-            for (int p = p0; p < p1; ++p) e->prof_flops += fr * 2.0 * C * 2.0 * C * ((p & 1) ? 1.0 : (double)e->K);
-            e->prof_name = "stack_kernel<" + std::to_string(stack_ni) + "> (fused residual stack: dilated conv k=" +
-                           std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
-                           std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) + ")";
+        for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
+        const long act_n = (long)Cp * T, c_bs = (long)2 * Cp * T;
+        int b0 = 0;
+        for (int ck = 0; ck < stack_chunks; ++ck) {
+            const int nb = NB / stack_chunks + (ck < NB % stack_chunks ? 1 : 0);      // balanced chunk sizes
+            StackArgs sa{};
+            sa.h = e->h + b0 * act_n; sa.hd = e->hd + b0 * act_n; sa.g = e->g + b0 * act_n; sa.skip = e->skip + b0 * act_n;
+            sa.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
+            sa.tsel = tsel ? tsel + b0 : nullptr; sa.d2_ts = (long)L * Cp;
+            sa.zero = zero_vec();
+            sa.NB = nb; sa.T = T; sa.Cp = Cp; sa.taps = e->K; sa.L = L;
+            sa.n_cond = std::max(0, std::min(nb, n_cond - b0));
+            sa.c_bs = c_bs;
+            sa.p0 = p0; sa.p1 = p1;
+            sa.xcd_n = e->opt_stack_xcd;
+            sa.warm = e->opt_stack_warm;
+            sa.fault = e->opt_stack_fault;
+            sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
+            sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
+            for (int l = 0; l < L; ++l) {
+                const LayerW& w = e->layers[l];
+                StackLayer& y = sa.layer[l];
+                y.conv_w = w.conv_w; y.conv_b = w.conv_b;
+                y.conv_b2 = zero_spec ? w.conv_b_z : w.conv_b_u;
+                y.cond2 = nullptr;
+                if (e->cond_tr && !zero_spec) { y.cond2 = e->cond_tr + (size_t)l * 2 * Cp * T; y.conv_b2 = w.conv_b; }
+                // conditional samples of this chunk start at sample b0 of the layer's conditioner tensor (a chunk
+                // without any keeps a readable pointer: the kernel prefetches, then ignores it)
+                y.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T + (b0 < n_cond ? (size_t)b0 * c_bs : 0)
+                                 : e->cond_dummy;
+                y.out_w = w.out_w; y.out_b = w.out_b; y.dil = w.dil;
+            }
+            const bool timed = e->prof && e->prof_used < e->prof_events.size();
+            if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
+            HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
+            e->stack_launches += 1;
+            if (timed) {
+                HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
+                const double C = e->C, fr = (double)nb * T;
+                for (int p = p0; p < p1; ++p) e->prof_flops += fr * 2.0 * C * 2.0 * C * ((p & 1) ? 1.0 : (double)e->K);
+                e->prof_name = "stack_kernel<" + std::to_string(stack_ni) + "> (fused residual stack: dilated conv k=" +
+                               std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
+                               std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) +
+                               (stack_chunks > 1 ? ", " + std::to_string(stack_chunks) + " sample chunks" : "") + ")";
+            }
+            b0 += nb;
         }
         return DR_OK;
     };

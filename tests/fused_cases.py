@@ -26,12 +26,15 @@ CASES = {
         (512, 2, 9, 8, 128, "generation_ddpm_x0"),  # full width, two 64-frame tiles per clip
         (512, 2, 9, 3, 300, "ddpm_x0"),             # full width, 5 tiles per clip (group of 40 blocks)
         (512, 3, 15, 16, 64, "cfdg_ddpm_x0"),       # 32 evaluations x 8 M tiles = 256 blocks
+        (512, 2, 9, 40, 125, "ddpm_x0"),            # 40 evaluations x 16 blocks: three fused launches of 14 / 13 / 13 samples
+        (512, 2, 9, 20, 125, "cfdg_ddpm_x0"),       # ... the middle chunk holds conditional AND unconditional samples
     ],
     2: [  # 128-frame blocks (chosen when 64-frame blocks would not fit the chip in one round)
         (512, 3, 9, 16, 125, "cfdg_ddpm_x0"),       # the bench geometry: 32 evaluations, one tile per clip
         (512, 2, 9, 8, 250, "cfdg_ddpm_x0"),        # 16 evaluations x 2 tiles x 8 M tiles = 256 blocks, halo exchange
         (512, 2, 15, 16, 200, "generation_ddpm_x0"),
         (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
+        (512, 2, 9, 32, 125, "cfdg_ddpm_x0"),       # 64 evaluations: two fused launches (all conditional / all unconditional)
     ],
     5: [  # 160-frame blocks on the 16x16x4 MFMA (DR_STACK_FL=5: measured slower than per-phase launches, kept tested)
         (512, 2, 15, 4, 640, "cfdg_ddpm_x0"),       # BASELINE config 5 per-GPU geometry: 8 evaluations x 4 tiles x 8 M tiles
