@@ -55,6 +55,14 @@ CONFIGS = {
                  "4 GPUs = 16 per GPU, hipGraph-captured chain"),
     5: dict(k=15, S=200, B=4, L=327680, sampler="cfdg_ddpm_x0", evals=2, gpus_named=8,
             what="configs[4]: k=15, 640-frame segments, cfdg_ddpm_x0 w=0.5, 200 steps, batch 32 over 8 GPUs = 4 per GPU"),
+    # the reference's own shipping geometry: sampling.py:27 draws x_T = randn(S, 1, 640, 88) (20.48 s segments) and
+    # config/sampling.yaml:11 sets batch_size 4; SURVEY.md 8d asks for config 3 "also at T=640"
+    6: dict(k=9, S=200, B=4, L=327680, sampler="cfdg_ddpm_x0", evals=2, gpus_named=1,
+            what="reference shipping geometry (sampling.py:27, config/sampling.yaml:11): k=9 transcription, cfdg_ddpm_x0 "
+                 "w=0.5, 200 steps, batch 4 of 640-frame (20.48 s) segments"),
+    7: dict(k=9, S=200, B=16, L=327680, sampler="generation_ddpm_x0", evals=1, gpus_named=8,
+            what="configs[2] at the reference's own generation length (sampling.py:27,45; SURVEY.md 8d): k=9 unconditional "
+                 "generation, 200 steps, 640-frame rolls, batch 16 per GPU"),
 }
 # module-level aliases of the default workload (tools/ import them)
 B_LOCAL = CONFIGS[2]["B"]
@@ -117,6 +125,18 @@ def pmc_traffic(kernel_tag):
 def flops_per_frame_eval(k, C=512, Lr=15):
     """algorithmic FLOPs per frame per network evaluation (conditioner / embedding hoisted)."""
     return 2 * 88 * C + Lr * (2 * C * 2 * C * k + 2 * C * 2 * C) + 2 * C * C + 2 * C * 88
+
+
+def executed_flops_per_chain(cfg, T, C=512, Lr=15):
+    """FLOPs the engine actually EXECUTES for one chain of the local batch: the algorithmic count (two full
+    evaluations per guided step) minus what it legitimately never computes - the first residual layer's dilated conv
+    of the unconditional half (same x_t: contracted once per (conditional, unconditional) pair) and the residual half
+    of the last layer's 1x1 (model/diffwave.py:678-682 only reads the skip sum after the loop)."""
+    B, S, k, ev = cfg["B"], cfg["S"], cfg["k"], cfg["evals"]
+    algo = flops_per_frame_eval(k, C, Lr) * B * T * ev * S
+    shared_conv = (2 * C * 2 * C * k) * B * T * S if ev == 2 else 0
+    unused_res = (2 * C * C) * B * T * ev * S
+    return algo - shared_conv - unused_res
 
 
 def chain_bytes(cfg, T):
@@ -282,7 +302,13 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    fb0 = model.engine.fallbacks
     dt, out = timed(args.steps)
+    if model.engine.fallbacks != fb0:
+        # a fused launch timed out inside the timed region and was healed by re-running on the per-phase kernels:
+        # the rolls are right, but the time is not a measurement of the engine - fail the line instead of printing it
+        raise SystemExit(f"rank {rank}: a fused residual-stack launch timed out during the timed region (is something else "
+                         "using this GPU?): no benchmark line")
 
     frames = world * B * T * args.steps
     result = {
@@ -297,7 +323,33 @@ def main():
                    "kernel_size": cfg["k"], "sampler": sampler, "w": W_CFG if cfg["evals"] == 2 else None,
                    "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True},
         "dist": launch.dist_info(dist),
+        "fused_fallbacks": 0,
     }
+    # straggler visibility for the scaling table: every rank's own time over the same K steps (no barrier inside),
+    # and the final all-gather on its own (HIP events around 10 back-to-back gathers of the finished rolls)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    mine = torch.tensor([1e3 * (time.perf_counter() - t0) / args.steps], device=device, dtype=torch.float64)
+    if dist is not None:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [float(v.item()) for v in allr]
+    else:
+        per_rank = [float(mine.item())]
+    roll_l, _ = model.sample(x_T, wav, seed=0, first_sample=rank * B)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gather_rolls(roll_l)
+    sync()
+    e0.record()
+    for _ in range(10):
+        gather_rolls(roll_l)
+    e1.record()
+    torch.cuda.synchronize()
+    result["per_rank_ms_per_step"] = {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
+                                      "all": [round(v, 3) for v in per_rank]}
+    result["gather_us"] = round(1e3 * e0.elapsed_time(e1) / 10, 2) if dist is not None else 0.0
     if rank == 0:
         assert out is not None and bool(torch.isfinite(out).all()) and out.shape == (world * B, 1, T, 88)
         # the metric also asks for the HBM-roofline fraction: SURVEY.md 8(d) algorithmic bytes of one chain per GPU
@@ -308,9 +360,17 @@ def main():
         result["hbm_roofline"] = {"algorithmic_bytes_per_chain_per_gpu": cb, "achieved_gbps_per_gpu": round(gbps, 1),
                                   "peak_gbps": PEAK_HBM_GBPS, "frac": round(gbps / PEAK_HBM_GBPS, 4),
                                   "note": "the step is MFMA-bound in fp32 (see roofline); reported because the metric names it"}
-        result["whole_chain"] = {"algorithmic_tflop_per_chain_per_gpu": round(fl / 1e12, 2),
-                                 "achieved_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 2),
-                                 "frac_of_fp32_mfma_peak": round(fl / (dt / args.steps) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)}
+        fx = executed_flops_per_chain(cfg, T)
+        per = dt / args.steps
+        result["whole_chain"] = {
+            "algorithmic_tflop_per_chain_per_gpu": round(fl / 1e12, 2),
+            "algorithmic_tflops_per_gpu": round(fl / per / 1e12, 2),
+            "algorithmic_frac_of_fp32_mfma_peak": round(fl / per / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+            "executed_tflop_per_chain_per_gpu": round(fx / 1e12, 2),
+            "executed_tflops_per_gpu": round(fx / per / 1e12, 2),
+            "executed_frac_of_fp32_mfma_peak": round(fx / per / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+            "note": "algorithmic = SURVEY.md 8d count (two full evaluations per guided step); executed = minus the shared "
+                    "first-layer contraction and the never-read residual half of the last 1x1 (work the engine does not do)"}
 
     if rank == 0 and not args.no_roofline:
         eng = model.engine

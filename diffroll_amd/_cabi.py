@@ -11,8 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 6
-DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME = 0, -1, -2, -3, -4, -5
+DR_ABI_VERSION = 7
+DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME, DR_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 
 SAMPLERS = {
     "ddpm_x0": 0,
@@ -37,7 +37,7 @@ EXPORTS = [
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
     "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
-    "dr_gather",
+    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power",
 ]
 
 
@@ -92,6 +92,13 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_step.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, vp]
     lib.dr_sample.restype = C.c_int
     lib.dr_sample.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, vp]
+    lib.dr_finish.restype = C.c_int
+    lib.dr_finish.argtypes = [vp, vp]
+    lib.dr_sample_checked.restype = C.c_int
+    lib.dr_sample_checked.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int,
+                                      C.POINTER(C.c_int32), vp]
+    lib.dr_stack_fallbacks.restype = C.c_int
+    lib.dr_stack_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.dr_frame_counts.restype = C.c_int
     lib.dr_frame_counts.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_int64), vp]
     lib.dr_note_runs.restype = C.c_int
@@ -99,6 +106,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     for fn in (lib.dr_q_sample, lib.dr_extract_x0):
         fn.restype = C.c_int
         fn.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp]
+    lib.dr_debug_stft_power.restype = C.c_int
+    lib.dr_debug_stft_power.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.dr_set_spec_norm.restype = C.c_int
     lib.dr_set_spec_norm.argtypes = [vp, C.c_int]
     lib.dr_set_precision.restype = C.c_int

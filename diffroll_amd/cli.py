@@ -142,8 +142,16 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
         # N ranks here, one process per GPU
         if argv is not None:      # called as a function: there is no command line to re-execute
             raise SystemExit(f"gpus={gpus}: start the {gpus} ranks with torch.distributed.run (or run the driver script)")
+        # (`python -m diffroll_amd.cli ...`: sys.argv[0] is this file, which cannot run as a plain script - relative
+        # imports - so the ranks are started as the same module)
+        main_mod = sys.modules.get("__main__")
+        spec = getattr(main_mod, "__spec__", None)
+        if spec is not None and spec.name and spec.name.startswith("diffroll_amd."):
+            raise SystemExit(launch.spawn_ranks(gpus, spec.name, list(sys.argv[1:]), module=True))
         raise SystemExit(launch.spawn_ranks(gpus, os.path.abspath(sys.argv[0]), list(sys.argv[1:])))
     rank, world, local_rank = launch.rank_env()
+    if launch.under_launcher() and world != gpus:
+        raise SystemExit(f"gpus={gpus} but the launcher started WORLD_SIZE={world} ranks")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = launch.init_process_group(device) if world > 1 else None

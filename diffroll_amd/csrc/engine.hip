@@ -115,10 +115,14 @@ struct dr_engine {
     int opt_stack_fault = 0;            // test hook (option "stack_fault_test")
     int opt_stack_warm = 0;             // idle waves of the fused kernel warm the L2 for the next phase (measured: +-0)
     int n_cus = 0;
-    unsigned* stack_bar = nullptr;      // [STACK_GROUPS][2] group counters, zero between launches
+    unsigned* stack_bar = nullptr;      // [STACK_GROUPS][4] {arrivals, departures, generation, -}: the first two zero between launches
     unsigned* stack_err = nullptr;      // device address of the time-out flag (host-mapped memory)
     volatile unsigned* stack_err_host = nullptr;
-    unsigned* stack_xid = nullptr;      // [n_cus-sized] XCC ids published by the blocks of the last launch
+    unsigned* stack_derr = nullptr;     // the same flag in device memory (what the kernels poll / test at launch start)
+    unsigned* stack_xid = nullptr;      // [1024] (generation, XCC id) tags published by the blocks of the last launch
+    int64_t stack_fallbacks = 0;        // time-outs detected by dr_finish: each one switched this engine to per-phase launches
+    float* xsave = nullptr;             // dr_sample_checked: copy of x_T, so that a timed-out chain can be re-run
+    size_t xsave_cap = 0;
     long long* stack_dbg = nullptr;     // phase tick marks of block 0 (dr_debug_stack_ticks)
     int stack_dbg_on = 0;
     int64_t stack_launches = 0;         // fused-kernel launches issued (captured launches count once, at capture)
@@ -568,7 +572,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             sa.xcd_n = e->opt_stack_xcd;
             sa.warm = e->opt_stack_warm;
             sa.fault = e->opt_stack_fault;
-            sa.bar = e->stack_bar; sa.err = e->stack_err; sa.xid = e->stack_xid;
+            sa.bar = e->stack_bar; sa.err = e->stack_err; sa.derr = e->stack_derr; sa.xid = e->stack_xid;
             sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
             for (int l = 0; l < L; ++l) {
                 const LayerW& w = e->layers[l];
@@ -590,7 +594,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if (timed) {
                 HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
                 const double C = e->C, fr = (double)nb * T;
-                for (int p = p0; p < p1; ++p) e->prof_flops += fr * 2.0 * C * 2.0 * C * ((p & 1) ? 1.0 : (double)e->K);
+                // executed work only: the last layer's 1x1 computes its skip half alone (the residual half is never read)
+                for (int p = p0; p < p1; ++p)
+                    e->prof_flops += fr * 2.0 * C * 2.0 * C * ((p & 1) ? (p == 2 * L - 1 ? 0.5 : 1.0) : (double)e->K);
                 e->prof_name = "stack_kernel<" + std::to_string(stack_ni) + "> (fused residual stack: dilated conv k=" +
                                std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
                                std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) +
@@ -726,12 +732,28 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
     return DR_OK;
 }
 
+// After a barrier time-out (device idle): re-arm the group counters, forget the published XCC tags, lower both flags.
+int clear_stack_timeout(dr_engine* e) {
+    HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(4 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));
+    HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));
+    HIPCHK(e, hipMemset(e->stack_derr, 0, 16 * sizeof(unsigned)));
+    *e->stack_err_host = 0;
+    return DR_OK;
+}
+
+void drop_graph(dr_engine* e) {
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
+    e->gkey = GraphKey{};
+}
+
 int check_ready(dr_engine* e, int sampler, int B, int T) {
     if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
     if (e->stack_err_host && *e->stack_err_host)
-        return fail(e, DR_EHIP, "a group barrier of an earlier fused residual-stack launch timed out (its results are invalid): "
-                                "is another stream / engine computing on this device at the same time? set option "
-                                "fused_stack = 0 for that, and call dr_stack_status to clear the condition");
+        return fail(e, DR_ETIMEOUT, "a group barrier of an earlier fused residual-stack launch timed out (the results since the "
+                                    "last dr_finish are invalid): is another stream / engine computing on this device at the "
+                                    "same time? call dr_finish (or dr_stack_status) to clear the condition and recompute - "
+                                    "dr_finish also switches this engine to per-phase launches; dr_sample_checked does all of that");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
     if (sampler != DR_SAMPLER_GENERATION_DDPM_X0 && (e->fe_B != B || e->fe_T != T))
         return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
@@ -821,6 +843,7 @@ void dr_destroy(dr_engine* e) {
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
     if (e->stack_bar) (void)hipFree(e->stack_bar);
+    if (e->xsave) (void)hipFree(e->xsave);
     if (e->stack_err_host) (void)hipHostFree((void*)e->stack_err_host);
     if (e->stack_dbg) (void)hipFree(e->stack_dbg);
     if (e->sk_cnt) (void)hipFree(e->sk_cnt);
@@ -1053,11 +1076,13 @@ int dr_commit(dr_engine* e, void* stream) {
     if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
     if (!e->stack_bar) {     // group counters of the fused residual stack: zero between launches (re-armed in-kernel)
         void* q = nullptr;
-        const size_t nb = (size_t)(2 * dr_engine::STACK_GROUPS + 1024) * sizeof(unsigned);
+        const size_t nb = (size_t)(4 * dr_engine::STACK_GROUPS + 1024 + 16) * sizeof(unsigned);
         HIPCHK(e, hipMalloc(&q, nb));
         HIPCHK(e, hipMemset(q, 0, nb));
         e->stack_bar = (unsigned*)q;
-        e->stack_xid = e->stack_bar + 2 * dr_engine::STACK_GROUPS;      // one word per block (<= 1024 CUs)
+        e->stack_xid = e->stack_bar + 4 * dr_engine::STACK_GROUPS;      // one word per block (<= 1024 CUs)
+        e->stack_derr = e->stack_xid + 1024;
+        HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));   // no tag of a launch ever equals 0xFFFFFFFF
         // the "a barrier wait gave up" flag lives in host-visible memory: every later API call sees it without a
         // synchronisation and fails loudly instead of returning rolls computed from a broken hand-off
         void* hf = nullptr;
@@ -1305,6 +1330,74 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     return DR_OK;
 }
 
+int dr_finish(dr_engine* e, void* stream) {
+    if (!e) return DR_EINVAL;
+    DeviceGuard guard(e->cfg.device);
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    if (!e->stack_err_host || !*e->stack_err_host) return DR_OK;
+    // A group barrier of the fused kernel gave up: something else held CUs while it ran (another engine / stream /
+    // process on this device).  Everything computed since the last dr_finish is invalid.  Heal: wait for the
+    // device, re-arm, and run this engine on the per-phase kernels from now on (bit-identical results, no
+    // co-residency assumption) - the caller recomputes.
+    HIPCHK(e, hipDeviceSynchronize());
+    int rc = clear_stack_timeout(e);
+    if (rc) return rc;
+    drop_graph(e);
+    e->opt_stack = 0;
+    e->stack_fallbacks += 1;
+    static bool warned = false;
+    if (!warned) {
+        warned = true;
+        fprintf(stderr, "[diffroll_amd] a group barrier of the fused residual-stack kernel timed out (another stream, engine or "
+                        "process is computing on device %d): this engine now uses one launch per phase (option fused_stack = 0); "
+                        "results since the last check are recomputed\n", e->cfg.device);
+    }
+    return fail(e, DR_ETIMEOUT, "a fused residual-stack launch timed out: results since the last dr_finish are invalid and must be "
+                                "recomputed; the engine has been switched to per-phase launches (fused_stack = 0)");
+}
+
+int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, float w, uint64_t seed,
+                      int first_sample, int use_graph, int32_t* recovered, void* stream) {
+    if (recovered) *recovered = 0;
+    if (!e || !d_x) return fail(e, DR_EINVAL, "null argument");
+    if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
+    DeviceGuard guard(e->cfg.device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t per = (size_t)B * T * 88;
+    const bool may_fuse = e->opt_stack != 0;
+    if (may_fuse) {       // only a fused launch can time out: keep x_T so that the chain can be re-run
+        if (per > e->xsave_cap) {
+            HIPCHK(e, hipStreamSynchronize(st));
+            int rc = dev_alloc(e, &e->xsave, per, false);
+            if (rc) return rc;
+            e->xsave_cap = per;
+        }
+        HIPCHK(e, hipMemcpyAsync(e->xsave, d_x, per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    int rc = dr_sample(e, sampler, d_x, d_noise, B, T, w, seed, first_sample, use_graph, st);
+    if (rc == DR_ETIMEOUT) {          // a flag left by unchecked earlier calls: clear it and carry on (nothing of THIS call ran)
+        (void)dr_finish(e, st);
+        rc = dr_sample(e, sampler, d_x, d_noise, B, T, w, seed, first_sample, use_graph, st);
+    }
+    if (rc) return rc;
+    rc = dr_finish(e, st);
+    if (rc != DR_ETIMEOUT) return rc;
+    if (!may_fuse) return rc;         // cannot happen: no fused launch was issued
+    HIPCHK(e, hipMemcpyAsync(d_x, e->xsave, per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    rc = dr_sample(e, sampler, d_x, d_noise, B, T, w, seed, first_sample, use_graph, st);     // per-phase kernels now
+    if (rc) return rc;
+    rc = dr_finish(e, st);
+    if (rc == DR_OK && recovered) *recovered = 1;
+    if (rc == DR_OK) e->err.clear();
+    return rc;
+}
+
+int dr_stack_fallbacks(dr_engine* e, int64_t* count) {
+    if (!e || !count) return DR_EINVAL;
+    *count = e->stack_fallbacks;
+    return DR_OK;
+}
+
 int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end, void* stream) {
     if (!e || !d_roll || !d_note_end) return fail(e, DR_EINVAL, "null argument");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
@@ -1421,8 +1514,8 @@ int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t
     if (timed_out) *timed_out = (int32_t)flag;
     if (launches) *launches = e->stack_launches;
     if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
-        HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(2 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));
-        *e->stack_err_host = 0;
+        int rc = clear_stack_timeout(e);
+        if (rc) return rc;
     }
     if (ticks && n_ticks > 0) {
         long long h[128];
@@ -1501,6 +1594,31 @@ int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream) {
     a.dbg = e->dbg_ticks;
     allow_splitk(e, a);
     HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, pick_pointwise_tile(Cp / 64, NB, T, e->prec), (hipStream_t)stream, e->prec));
+    return DR_OK;
+}
+
+int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d_power_out, void* stream) {
+    if (!e || !d_wav || !d_power_out) return fail(e, DR_EINVAL, "null argument");
+    if (!e->committed) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    if (!e->use_fft) return fail(e, DR_ESTATE, "n_fft = %d is not a power of two: the spectrum is a windowed-DFT GEMM, not the FFT kernel", e->cfg.n_fft);
+    DeviceGuard guard(e->cfg.device);
+    hipStream_t st = (hipStream_t)stream;
+    const int N = e->cfg.n_fft, hop = e->cfg.hop_length, pad = N / 2;
+    if (B <= 0 || L <= pad) return fail(e, DR_EINVAL, "bad front-end shape B=%d L=%d", B, L);
+    const int TF = L / hop + 1, Lp = (L + 2 * pad + 3) & ~3, bp = e->bins_p;
+    float *wp = nullptr, *pw = nullptr;        // private buffers: the engine's front-end state is left alone
+    int rc;
+    if ((rc = dev_alloc(e, &wp, (size_t)B * Lp, false))) return rc;
+    if ((rc = dev_alloc(e, &pw, (size_t)B * bp * TF, false))) { (void)hipFree(wp); return rc; }
+    hipError_t he = launch_reflect_pad(d_wav, wp, B, L, pad, st);
+    if (he == hipSuccess) he = launch_stft_power(wp, e->fft_win, e->fft_tw, pw, B, Lp, TF, N, hop, bp, e->fft_norm, st);
+    if (he == hipSuccess)
+        he = hipMemcpy2DAsync(d_power_out, (size_t)e->n_bins * 4, pw, (size_t)bp * 4, (size_t)e->n_bins * 4, (size_t)B * TF,
+                              hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    (void)hipFree(wp);
+    (void)hipFree(pw);
+    if (he != hipSuccess) return fail(e, DR_EHIP, "dr_debug_stft_power: %s", hipGetErrorString(he));
     return DR_OK;
 }
 

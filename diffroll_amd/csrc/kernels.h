@@ -128,8 +128,12 @@ struct StackArgs {
     int fault;                                // test hook: barriers wait for one arrival too many (exercises the spin bound)
     int warm;                                 // idle waves warm the L2 with the next phase's weights / conditioner tile
     unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)
-    unsigned* bar;                            // [groups][2] arrival / departure counters, all zero between launches
-    unsigned* err;                            // set to 1 if a barrier wait ran into its spin bound (never in a healthy run)
+    unsigned* bar;                            // [groups][4] {arrivals, departures, generation, -}; the first two are zero
+                                              // between launches, the generation advances by one per launch
+    unsigned* err;                            // host-mapped: set to 1 if a barrier wait ran into its spin bound (never in a
+                                              // healthy run)
+    unsigned* derr;                           // device copy of that flag: polled by the waits, and a launch that finds it set
+                                              // returns at once (cleared by the host together with *err)
     long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
     StackLayer layer[DR_STACK_MAX_LAYERS];
 };

@@ -1036,8 +1036,13 @@ DR_DEVINL void l2_touch(const float* base, const unsigned bytes, const int part,
     asm volatile("" ::"v"(acc));
 }
 
+// Spins are bounded.  A wait that runs into the bound (~1 s of polling; a phase lasts < 1 ms) raises BOTH flags -
+// *err (host-mapped: the host sees it without a copy, dr_finish / dr_stack_status) and *derr (device memory: what
+// the kernels themselves poll) - and carries on with wrong data; every other wait of the launch then gives up
+// within ~64 polls (it looks at *derr after 64 polls and every 4096 after), and every later fused launch of the
+// engine returns at its first instruction (stack_kernel) until the host has cleared the condition.
 template <bool ACQUIRE>
-DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err) {
+DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err, unsigned* derr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // EVERY wave: its stores (incl. the asm sc1 ones) are out
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1045,10 +1050,11 @@ DR_DEVINL void group_barrier(unsigned* ctr, const unsigned target, unsigned* err
         unsigned spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(4);
-            // ~1 s of polling (a phase lasts < 1 ms), or another wait already gave up: flag it and carry on
-            // (*err is host-mapped memory: system scope)
-            if (++spins > (1u << 20) || ((spins & 4095u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM))) {
+            ++spins;
+            if (spins > (1u << 20) ||
+                ((spins == 64u || (spins & 4095u) == 0) && __hip_atomic_load(derr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(derr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
@@ -1092,7 +1098,12 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     }
     mt = member % MT;                                     // sample (clip evaluation) grp = barrier group
     nt = grp * tps + member / MT;
-    unsigned* ctr = s.bar + 2 * grp;
+    // A time-out of an earlier launch of this engine that the host has not cleared yet (dr_finish / dr_stack_status):
+    // do nothing at all - the chain's remaining launches drain in microseconds and the caller re-runs the sample on
+    // the per-phase kernels.  (Written by an EARLIER kernel of the stream: visible across the kernel boundary.)
+    // (the flag is requested here and tested after the resident tile's loads are issued: its latency hides there)
+    const unsigned pending_timeout = __hip_atomic_load(s.derr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned* ctr = s.bar + 4 * grp;                      // {arrivals, departures, generation, -}
     const long act_bs = (long)s.Cp * s.T;
     const int P = s.Cp >> 2;
     unsigned episode = 0;
@@ -1123,6 +1134,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             if (seg * 64 + lane < BN)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0_ + seg * 64 + lane) * 16, 0, 0, 0);
         }
+        if (pending_timeout) return;
         // (the first group barrier - or the end of a one-phase launch - drains these loads: s_waitcnt vmcnt(0)
         // + __syncthreads(); a launch that STARTS with a 1x1 phase waits right here)
         if (s.p0 & 1) {
@@ -1130,11 +1142,19 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             __syncthreads();
         }
     }
+    // The published word carries the group's GENERATION (a counter the last block to leave a launch advances, read
+    // here with a returning agent-scope atomic, i.e. at the coherence point): a word left behind by any earlier
+    // launch - whatever cache it might be served from - can never compare equal to this launch's, it reads as
+    // "not my XCD" and the group keeps the write-through stores that are valid under every placement.
     int wt_store = 1;
+    unsigned my_tag = 0;
+    __shared__ unsigned same_xcd_s;
     if (threadIdx.x == 0) {
         unsigned my_xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
-        __hip_atomic_store(s.xid + (long)grp * gsize + member, my_xcc & 0xfu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned gen = __hip_atomic_fetch_add(ctr + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        my_tag = (gen << 4) | (my_xcc & 0xfu);
+        __hip_atomic_store(s.xid + (long)grp * gsize + member, my_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
 #pragma unroll 1
@@ -1206,15 +1226,16 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // (no acquire here: a conv phase reads hd with L1-bypassing sc1 LDS-DMA loads, and the 1x1 phase's L1
             // invalidate was issued by a producer wave during the conv phase, above)
             // (s.fault: test hook - one arrival more than the group has is awaited, so every wait runs into its bound)
-            group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err);
-            if (episode == 1) {      // every block of the group has published its XCC id: one L2 for all of them?
-                unsigned mine;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
-                mine &= 0xfu;
-                int same = 1;
-                for (unsigned i = 0; i < gsize; ++i)
-                    same &= (__hip_atomic_load(s.xid + (long)grp * gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
-                wt_store = __builtin_amdgcn_readfirstlane(same ? 0 : 1);     // wave-uniform (every lane read the same words)
+            group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err, s.derr);
+            if (episode == 1) {      // every block of the group has published its (generation, XCC id): one L2 for all?
+                if (threadIdx.x == 0) {
+                    unsigned same = 1;
+                    for (unsigned i = 0; i < gsize; ++i)
+                        same &= (__hip_atomic_load(s.xid + (long)grp * gsize + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_tag);
+                    same_xcd_s = same;
+                }
+                __syncthreads();
+                wt_store = __builtin_amdgcn_readfirstlane(same_xcd_s ? 0 : 1);     // block-uniform
             }
         }
     }
@@ -1240,6 +1261,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         if (left == gsize - 1) {
             __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(ctr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // next generation
         }
     }
 }
@@ -1626,6 +1648,8 @@ static hipError_t init_gemm_ni() {
     if ((e = init_gemm_t<NI, KS, EPI_POWER, 0>()) != hipSuccess) return e;
     return init_gemm_t<NI, KS, EPI_LOG, 0>();
 }
+__global__ void stft_power_kernel(const float* __restrict__ wav_pad, const float* __restrict__ win, const float2* __restrict__ tw,
+                                  float* __restrict__ power, int Lp, int TF, int N, int hop, int bins_p, float norm);   // below
 // allow > 64 KiB of dynamic LDS for every instantiation; call once per process before any launch
 // (and never inside a stream capture)
 hipError_t init_kernels() {
@@ -1641,6 +1665,8 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
+    // the FFT front-end holds two n_fft/2-point complex buffers: n_fft * 8 bytes (128 KiB at its largest size, 16384)
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_power_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

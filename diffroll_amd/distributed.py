@@ -63,6 +63,8 @@ class NativeComm:
         from . import _cabi
         self.lib = _cabi.load_library()
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:      # 'cuda' == the current device: compare indexed
+            self.device = torch.device("cuda", torch.cuda.current_device())
         d = _dist()
         if rank is None or world_size is None:
             rank, world_size = (d.get_rank(group), d.get_world_size(group)) if d else (0, 1)
@@ -159,11 +161,9 @@ def sample_shard(model, x_T: torch.Tensor, waveform: Optional[torch.Tensor], noi
     if hi > lo:
         roll, _ = model.sample(x_T[lo:hi], wav, noise=z, seed=seed, first_sample=lo)
         return roll
-    # more ranks than clips: an empty shard with the frame count the other ranks will produce
-    T = x_T.shape[2]
-    hop = getattr(model.engine, "hop_length", None)
-    if waveform is not None and hop:
-        T = min(T, waveform.shape[-1] // hop + 1)       # trim_spec_roll, model/diffwave.py:30-39
+    # more ranks than clips: an empty shard with the frame count the other ranks will produce (the model's own rule:
+    # trim_spec_roll incl. the 641-frame learned spectrogram of condition='trainable_spec')
+    T = model.output_frames(x_T.shape[2], None if waveform is None else waveform.shape[-1])
     return torch.zeros((0, 1, T, x_T.shape[3]), dtype=torch.float32, device=model.engine.device)
 
 

@@ -18,6 +18,12 @@ class EngineError(RuntimeError):
     pass
 
 
+class EngineTimeout(EngineError):
+    """A group barrier of the fused residual-stack kernel ran into its spin bound (DR_ETIMEOUT): the results since
+    the last finish() are invalid.  finish() has already cleared the condition and switched the engine to per-phase
+    launches, so recomputing is safe; sample(check=True) does that by itself and never raises this."""
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -99,6 +105,8 @@ class Engine:
             msg = self.lib.dr_last_error(self.h).decode()
             if rc in (_cabi.DR_EINVAL, _cabi.DR_ENAME):
                 raise ValueError(msg)
+            if rc == _cabi.DR_ETIMEOUT:
+                raise EngineTimeout(f"[{rc}] {msg}")
             raise EngineError(f"[{rc}] {msg}")
 
     def _stream(self) -> int:
@@ -148,6 +156,16 @@ class Engine:
                                              _ptr(spec), self._stream()))
         return spec
 
+    def stft_power(self, waveform: torch.Tensor) -> torch.Tensor:
+        """Diagnostic (dr_debug_stft_power): (B, L) -> power spectrogram (B, L // hop + 1, n_fft // 2 + 1) of the FFT
+        stage alone: reflect pad, windowed FFT, / sqrt(sum w^2), |.|^2."""
+        wav = self._dev(waveform)
+        B, L = wav.shape
+        out = torch.empty(B, L // self.hop_length + 1, self.n_fft // 2 + 1, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_debug_stft_power(self.h, wav.data_ptr(), B, L, out.data_ptr(), self._stream()))
+        return out
+
     def forward(self, x: torch.Tensor, t: int, uncond: bool) -> torch.Tensor:
         """x (B, T, 88) -> x0 (B, T, 88)."""
         x = self._dev(x)
@@ -184,9 +202,28 @@ class Engine:
                                          float(w), int(seed), int(first_sample), self._stream()))
         return x
 
+    def finish(self):
+        """Synchronise the current stream and verify that no fused residual-stack launch since the last check timed
+        out (include/diffroll_amd.h: dr_finish).  Raises EngineTimeout when one did - the engine has then already
+        been healed (per-phase launches from now on) and whatever was computed since the last check must be redone.
+        Call it before a roll obtained from forward() / step() / sample(check=False) is consumed."""
+        with torch.cuda.device(self.device):
+            self._check(self.lib.dr_finish(self.h, self._stream()))
+
+    @property
+    def fallbacks(self) -> int:
+        """How many fused-kernel time-outs this engine has detected and healed (0 in a healthy run)."""
+        n = C.c_int64(0)
+        self._check(self.lib.dr_stack_fallbacks(self.h, C.byref(n)))
+        return int(n.value)
+
     def sample(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], w: float = 0.0,
-               seed: int = 0, first_sample: int = 0, use_graph: bool = True) -> torch.Tensor:
-        """Whole reverse chain in place on x (B, T, 88); noise (S, B, T, 88) or None (Philox)."""
+               seed: int = 0, first_sample: int = 0, use_graph: bool = True, check: bool = True) -> torch.Tensor:
+        """Whole reverse chain in place on x (B, T, 88); noise (S, B, T, 88) or None (Philox).
+        check=True (default): synchronous and self-healing - returns only with the correct roll in x (a fused launch
+        that timed out because something else held the device's CUs is detected and the chain re-run on the per-phase
+        kernels, dr_sample_checked).  check=False: asynchronous on the current stream; call finish() before the
+        roll is consumed."""
         assert x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
         B, T, _ = x.shape
         if noise is not None:
@@ -195,9 +232,15 @@ class Engine:
         if use_graph:
             self._keep = [x, noise]
         with torch.cuda.device(self.device):
-            self._check(self.lib.dr_sample(self.h, _cabi.SAMPLERS[sampler], x.data_ptr(), _ptr(noise), B, T,
-                                           float(w), int(seed), int(first_sample), 1 if use_graph else 0,
-                                           self._stream()))
+            if check:
+                rec = C.c_int32(0)
+                self._check(self.lib.dr_sample_checked(self.h, _cabi.SAMPLERS[sampler], x.data_ptr(), _ptr(noise), B, T,
+                                                       float(w), int(seed), int(first_sample), 1 if use_graph else 0,
+                                                       C.byref(rec), self._stream()))
+            else:
+                self._check(self.lib.dr_sample(self.h, _cabi.SAMPLERS[sampler], x.data_ptr(), _ptr(noise), B, T,
+                                               float(w), int(seed), int(first_sample), 1 if use_graph else 0,
+                                               self._stream()))
         return x
 
     def frame_counts(self, pred: torch.Tensor, label: torch.Tensor, threshold: float) -> Tuple[int, int, int]:

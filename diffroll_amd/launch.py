@@ -36,9 +36,9 @@ def visible_gpus() -> int:
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
 
-def spawn_ranks(n: int, script: str, argv: List[str], port: Optional[int] = None) -> int:
-    """Run ``script argv`` as n local ranks under torch.distributed.run and return its exit code.  Fails with a
-    device-count message (not a launcher hint) when fewer than n GPUs are visible."""
+def spawn_ranks(n: int, script: str, argv: List[str], port: Optional[int] = None, module: bool = False) -> int:
+    """Run ``script argv`` (module=True: ``-m script argv``) as n local ranks under torch.distributed.run and return
+    its exit code.  Fails with a device-count message (not a launcher hint) when fewer than n GPUs are visible."""
     have = visible_gpus()
     if have < n:
         raise SystemExit(f"{os.path.basename(script)}: {n} GPUs requested but only {have} HIP device(s) visible "
@@ -49,7 +49,8 @@ def spawn_ranks(n: int, script: str, argv: List[str], port: Optional[int] = None
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["DR_SELF_SPAWNED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(port or free_port())]
+    cmd += (["--module", script] if module else [script]) + list(argv)
     return subprocess.call(cmd, env=env)
 
 

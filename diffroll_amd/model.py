@@ -314,10 +314,29 @@ class ClassifierFreeDiffRoll(nn.Module):
             Tm = spec.shape[-1]
         x = x_t.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous()
         if uniform:
-            x0 = eng.forward(x, t, uncond=(sampling is True))
+            x0 = self._verified(lambda: eng.forward(x, t, uncond=(sampling is True)))
         else:                                      # one step per sample, as the reference's step() calls forward
-            x0 = eng.forward_steps(x, steps, uncond=(sampling is True))
+            x0 = self._verified(lambda: eng.forward_steps(x, steps, uncond=(sampling is True)))
         return x0.unsqueeze(1), spec
+
+    def _verified(self, fn):
+        """Run fn (engine launches returning a result tensor) and hand the result out only after engine.finish() has
+        confirmed that no fused launch timed out; after a time-out (healed by finish(): per-phase launches from then
+        on) it is recomputed once.  The reference's methods return finished tensors - never silently invalid ones."""
+        from .engine import EngineTimeout
+        eng = self.engine
+        try:
+            out = fn()
+            eng.finish()
+            return out
+        except EngineTimeout:
+            try:                   # (a time-out left pending by earlier unchecked calls is cleared here)
+                eng.finish()
+            except EngineTimeout:
+                pass
+            out = fn()
+            eng.finish()
+            return out
 
     # ------------------------------------------------------------------ samplers (one step)
     def _one_step(self, sampler: str, x, waveform, t_index: int, noise=None):
@@ -333,14 +352,14 @@ class ClassifierFreeDiffRoll(nn.Module):
             Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
             if self.hparams.condition == "trainable_spec":
                 Tm = min(T, 641)
-        xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        x_in = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
         z = None
         if noise is not None:
             z = noise.to(eng.device, torch.float32).reshape(B, Tm, 88).contiguous()
         elif t_index > 0:
             z = torch.randn(B, Tm, 88, device=eng.device)   # reference: torch.randn_like(x), global generator
-        eng.step(sampler, xx, z, t_index, w)
+        xx = self._verified(lambda: eng.step(sampler, x_in.clone(), z, t_index, w))
         if spec is None:
             spec = self._uncond_spec(B, Tm)
         return xx.unsqueeze(1), spec
@@ -391,13 +410,29 @@ class ClassifierFreeDiffRoll(nn.Module):
         return self._one_step("ddim2ddpm", x, waveform, t_index, noise)
 
     # ------------------------------------------------------------------ whole chain
+    def output_frames(self, T: int, waveform_samples: Optional[int]) -> int:
+        """Frames of the roll sample() returns for a T-frame x_T (trim_spec_roll, model/diffwave.py:30-39, :662): the
+        spectrogram's length when that is shorter - the clip's L // hop + 1, or the 641 frames of the learned
+        unconditional spectrogram under condition='trainable_spec' for generation."""
+        sampler = self.hparams.sampling.type
+        hop = self._engine_kwargs["hop_length"]
+        if sampler != "generation_ddpm_x0":
+            return min(T, waveform_samples // hop + 1)
+        Tm = T if waveform_samples is None else min(T, waveform_samples // hop + 1)
+        if self.hparams.condition == "trainable_spec":
+            Tm = min(T, 641)
+        return Tm
+
     @torch.no_grad()
     def sample(self, x_T, waveform=None, noise=None, seed: int = 0, first_sample: int = 0,
-               use_graph: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+               use_graph: bool = True, check: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
         """The reverse chain t = timesteps-1 .. 0 (task/diffusion.py:528-534) on the device with no
         host round trip.  x_T (B,1,T,88); noise: None (on-device Philox keyed by seed and global
         sample index) or (timesteps, B, 1, T, 88) injected z's (row t is used at step t >= 1).
-        Returns (roll (B,1,T',88), spec (B,n_mels,T'))."""
+        Returns (roll (B,1,T',88), spec (B,n_mels,T')).
+        check=True (default): the call returns with the FINISHED, verified roll, as task/diffusion.py:528-538 does
+        (synchronous; a fused-kernel time-out caused by another tenant of the device is healed by re-running the chain
+        on the per-phase kernels - Engine.sample).  check=False: asynchronous; call engine.finish() before use."""
         eng = self.engine
         sampler = self.hparams.sampling.type
         B, _, T, _ = x_T.shape
@@ -423,7 +458,7 @@ class ClassifierFreeDiffRoll(nn.Module):
             if Tm != T or not z.is_contiguous():
                 z = z[:, :, :Tm, :].contiguous()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
-        eng.sample(sampler, xb, z, w, seed, first_sample, use_graph)
+        eng.sample(sampler, xb, z, w, seed, first_sample, use_graph, check)
         return xb.unsqueeze(1), spec
 
     def sample_trajectory(self, x_T, waveform=None, noise=None, seed: int = 0, first_sample: int = 0):
@@ -462,9 +497,9 @@ class ClassifierFreeDiffRoll(nn.Module):
             Tm = min(T, waveform.shape[-1] // eng.hop_length + 1) if waveform is not None else T
             if self.hparams.condition == "trainable_spec":
                 Tm = min(T, 641)
-        xx = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous().clone()
+        x_in = x.to(eng.device, torch.float32).squeeze(1)[:, :Tm, :].contiguous()
         w = float(self.hparams.sampling.get("w", 0.0)) if sampler in _GUIDED else 0.0
-        eng.step(sampler, xx, None, t_index, w, seed, first_sample)
+        xx = self._verified(lambda: eng.step(sampler, x_in.clone(), None, t_index, w, seed, first_sample))
         if spec is None:
             spec = self._uncond_spec(B, Tm)
         return xx.unsqueeze(1), spec

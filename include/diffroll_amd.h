@@ -16,7 +16,7 @@
  *                                          (model/diffwave.py:664-686, ResidualBlock :134-151)
  *   dr_step                                cfdg_ddpm_x0 / generation_ddpm_x0 / inpainting_ddpm_x0 /
  *                                          ddpm_x0 (task/diffusion.py:943-1025, :831-853)
- *   dr_sample                              the loop of predict_step / sampling
+ *   dr_sample / dr_sample_checked          the loop of predict_step / sampling
  *                                          (task/diffusion.py:528-534, :779-788)
  *
  * Conventions: plain C, no torch types.  All tensor arguments are BORROWED device pointers to
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 6
+#define DR_ABI_VERSION 7
 
 enum {
     DR_OK = 0,
@@ -44,7 +44,9 @@ enum {
     DR_ESTATE = -2,   /* call order (e.g. dr_forward before dr_commit / dr_frontend) */
     DR_EHIP = -3,     /* a HIP runtime call failed (message has the HIP error string) */
     DR_ENOMEM = -4,
-    DR_ENAME = -5     /* unknown parameter name / wrong shape in dr_set_param */
+    DR_ENAME = -5,    /* unknown parameter name / wrong shape in dr_set_param */
+    DR_ETIMEOUT = -6  /* a group barrier of the fused residual-stack kernel ran into its spin bound: the results
+                         computed since the last dr_finish are invalid (see dr_finish / dr_sample_checked) */
 };
 
 /* samplers: task/diffusion.py, bound at :255 by hparams.sampling.type */
@@ -196,6 +198,29 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
               float w, uint64_t seed, int first_sample, int use_graph, void* stream);
 
 /*
+ * Consume point of asynchronous results.  The fused residual-stack kernel (option "fused_stack") assumes that all
+ * its workgroups are resident on the device at once; when something else holds CUs while it runs (a second engine,
+ * stream or process computing on the same device) a group barrier can run into its spin bound - the launch then
+ * carries on with wrong data, raises a flag, and every later fused launch of the engine returns immediately.
+ * dr_finish synchronises `stream` and checks that flag:
+ *   DR_OK        everything issued on this engine since the last check is valid;
+ *   DR_ETIMEOUT  it is NOT: recompute it.  The condition has been cleared and the engine switched to one launch per
+ *                phase (fused_stack = 0: bit-identical results, no residency assumption), so the recomputation
+ *                cannot time out again; re-enable with dr_set_option when the device is the engine's own again.
+ * Call it before a roll produced by dr_forward / dr_step / dr_sample is used (copied to the host, written as MIDI,
+ * gathered).  Every other entry point refuses to start (DR_ETIMEOUT) while an unchecked time-out is pending.
+ */
+int dr_finish(dr_engine* e, void* stream);
+/* dr_sample + dr_finish + (on a time-out) the re-run of the chain from the same x_T on the per-phase kernels:
+ * returns DR_OK only with the correct roll in d_x.  Synchronous.  *recovered (optional) = 1 when the re-run was
+ * needed.  This is what a one-shot caller (sampling.py, predict_step) should use: task/diffusion.py:528-538 returns
+ * a finished roll, never a silently invalid one. */
+int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T,
+                      float w, uint64_t seed, int first_sample, int use_graph, int32_t* recovered, void* stream);
+/* how many time-outs dr_finish has detected (and healed) on this engine so far */
+int dr_stack_fallbacks(dr_engine* e, int64_t* count);
+
+/*
  * Roll -> notes, the scan of extract_notes_wo_velocity (task/diffusion.py:1185-1233) as the reference's
  * drivers call it (onsets == frames == the roll, one threshold, rule1): d_note_end (B, T, 88) int32
  * receives, at every (frame, pitch) where a note STARTS, the frame index at which it ends (exclusive),
@@ -228,6 +253,12 @@ int dr_q_sample(dr_engine* e, const float* d_x_start, const float* d_noise, cons
 int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, const int64_t* d_t,
                   const float* d_sac, const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out,
                   void* stream);
+
+/* Diagnostic: the FFT stage of dr_frontend on its own - reflect padding + windowed FFT + / sqrt(sum w^2) + |.|^2
+ * (torchaudio Spectrogram(center, reflect, normalized=True, power=2) = torch.stft + those two steps;
+ * model/diffwave.py:635,643) - d_wav (B, L) -> d_power_out (B, L / hop + 1, n_fft / 2 + 1) row-major.  Lets a test
+ * hold the FFT kernel to torch.stft directly.  n_fft must be a power of two.  Synchronises `stream`. */
+int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d_power_out, void* stream);
 
 /* Spectrogram normalisation of the following dr_frontend calls: the mode of Normalization(0, 1, norm_args[2])
  * (model/diffwave.py:632, model/utils.py:10-32) - min-max per clip ("imagewise", the default and the released
@@ -264,8 +295,9 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          config-2 chain, i.e. nothing, and 511.6 vs 486.3 ms at config 3 - the loads it would
  *                          speed up are already hidden, and with 64-frame blocks the extra traffic hurts).
  *   "stack_fault_test" [0] test hook: the fused kernel's group barriers await one arrival more than a group has, so
- *                          every wait runs into its spin bound (~1 s) - the launch ends, flags the time-out, and
- *                          the next call on the engine fails with DR_EHIP until dr_stack_status clears it.
+ *                          the first wait runs into its spin bound (~1 s) - the launch ends, flags the time-out,
+ *                          later fused launches return at once, dr_finish reports DR_ETIMEOUT and heals, and any
+ *                          other call fails with DR_ETIMEOUT until dr_finish / dr_stack_status has cleared it.
  *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
  */
 int dr_set_option(dr_engine* e, const char* name, int value);

@@ -19,6 +19,9 @@ class FakeModel:
     either injected or derived from (seed, global sample index)."""
     engine = FakeEngine()
 
+    def output_frames(self, T, waveform_samples):
+        return T
+
     def sample(self, x_T, waveform=None, noise=None, seed=0, first_sample=0, use_graph=True):
         B = x_T.shape[0]
         out = x_T.clone() * 0.5

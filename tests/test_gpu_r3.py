@@ -1,0 +1,443 @@
+"""Round-3 hardening of the GPU parity suite (``pytest -m gpu``; everything reaches the kernels through the C-ABI).
+
+  * a fused-kernel barrier time-out can never hand out a wrong roll: the consume points (sample / predict_step / the
+    samplers / forward) verify and re-run on the per-phase kernels (include/diffroll_amd.h: dr_finish,
+    dr_sample_checked), also with two engines computing on one device from two streams;
+  * the whole 200-step chain at the REAL BASELINE batches (config 2: 16 clips; config 5: a 640-frame clip at k = 15);
+  * the reference's shipping geometry (sampling.py:27: 640-frame rolls at k = 9), one step each;
+  * a "trained-regime" battery: weights scaled so that gates saturate and |h| reaches 1e2..1e3 - the HIP result is
+    held to a float64 evaluation of the oracle and must be as accurate as the reference's own fp32 arithmetic;
+  * the FFT kernel directly against torch.stft;
+  * hypothesis-driven shapes.
+"""
+import math
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffroll_ref as R
+from test_gpu_parity import ATOL_FWD, ATOL_SPEC, ATOL_STEP, make_model, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+# --------------------------------------------------------------------------------------------
+# fused-kernel time-outs: never a wrong roll
+# --------------------------------------------------------------------------------------------
+def _timeout_fixture():
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=128, residual_layers=2, kernel_size=3, timesteps=4)
+    p = R.synthetic_params(hp, seed=1)
+    m = make_model(hp, p, sampler="generation_ddpm_x0", w=0.0)
+    torch.manual_seed(0)
+    x = torch.randn(8, 1, 64, 88)
+    noise = torch.randn(4, 8, 1, 64, 88)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "generation_ddpm_x0", x, None, noise)
+    return m, x, noise, ref
+
+
+def test_sample_with_a_timed_out_fused_launch_returns_the_right_roll():
+    """stack_fault_test = 1 makes the first group barrier of every fused launch run into its spin bound.  ONE call of
+    m.sample() must still return the oracle-correct roll (or raise) - never the roll of the broken launch: the chain
+    drains, dr_finish sees the flag, the engine switches itself to per-phase launches and the chain is re-run."""
+    m, x, noise, ref = _timeout_fixture()
+    eng = m.engine
+    eng.set_option("fused_stack", 2)
+    good, _ = m.sample(x, None, noise=noise)
+    assert eng.fallbacks == 0 and maxdiff(good.cpu(), ref) <= ATOL_STEP
+    eng.set_option("stack_fault_test", 1)
+    t0 = time.perf_counter()
+    roll, _ = m.sample(x, None, noise=noise)                  # ONE call
+    assert time.perf_counter() - t0 < 60.0
+    assert maxdiff(roll.cpu(), ref) <= ATOL_STEP
+    assert eng.fallbacks == 1
+    # healed: the engine runs per-phase launches now - more calls just work, also through the other entry points
+    again, _ = m.sample(x, None, noise=noise)
+    assert torch.equal(again, roll) and eng.fallbacks == 1
+    step, _ = m.reverse_diffusion(x, None, 2, noise=noise[2])
+    assert bool(torch.isfinite(step).all())
+    # and the fused kernel can be switched back on once the device is the engine's own again
+    eng.set_option("stack_fault_test", 0)
+    eng.set_option("fused_stack", 2)
+    n0 = (eng.stack_status(), eng.stack_launches)[1]
+    back, _ = m.sample(x, None, noise=noise)
+    eng.stack_status()
+    assert eng.stack_launches > n0 and eng.fallbacks == 1
+    assert maxdiff(back.cpu(), ref) <= ATOL_STEP and maxdiff(back.cpu(), good.cpu()) == 0.0
+
+
+def test_one_step_and_forward_are_verified_too():
+    """The samplers' one-step methods and forward() hand out finished tensors as the reference does: with the fault
+    hook on, a single reverse_diffusion() / forward() call returns the right values (healed), never the broken ones."""
+    m, x, noise, _ = _timeout_fixture()
+    eng = m.engine
+    eng.set_option("fused_stack", 0)
+    want_step, _ = m.reverse_diffusion(x, None, 2, noise=noise[2])
+    wav0 = torch.zeros(8, 64 * 512)
+    want_fwd, _ = m(x, wav0, torch.tensor(3).repeat(8), sampling=True)
+    for call in ("step", "forward"):
+        eng.set_option("fused_stack", 2)
+        eng.set_option("stack_fault_test", 1)
+        fb = eng.fallbacks
+        if call == "step":
+            got, _ = m.reverse_diffusion(x, None, 2, noise=noise[2])
+            assert maxdiff(got.cpu(), want_step.cpu()) <= 5e-6
+        else:
+            got, _ = m(x, wav0, torch.tensor(3).repeat(8), sampling=True)
+            assert maxdiff(got.cpu(), want_fwd.cpu()) <= 5e-6
+        assert eng.fallbacks == fb + 1
+        eng.set_option("stack_fault_test", 0)
+
+
+def test_unchecked_timeout_is_loud_at_the_consume_point_and_heals():
+    """The asynchronous form: Engine.sample(check=False) returns at once; finish() is the consume point and raises
+    EngineTimeout after a time-out (having healed the engine); until then every other call refuses to start."""
+    from diffroll_amd.engine import EngineTimeout
+    m, x, noise, ref = _timeout_fixture()
+    eng = m.engine
+    xb = x.squeeze(1).to(eng.device).contiguous()
+    z = noise.reshape(4, 8, 64, 88).to(eng.device).contiguous()
+    eng.set_option("fused_stack", 2)
+    eng.set_option("stack_fault_test", 1)
+    work = xb.clone()
+    t0 = time.perf_counter()
+    eng.sample("generation_ddpm_x0", work, z, check=False)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 60.0
+    with pytest.raises(EngineTimeout):                        # pending and unchecked: nothing else may start
+        eng.step("generation_ddpm_x0", xb.clone(), z[2], 2)
+    with pytest.raises(EngineTimeout, match="recomputed"):
+        eng.finish()
+    assert eng.fallbacks == 1
+    eng.finish()                                              # cleared: a second check is clean
+    work = xb.clone()
+    eng.sample("generation_ddpm_x0", work, z, check=False)    # per-phase launches now
+    eng.finish()
+    assert maxdiff(work.cpu().unsqueeze(1), ref) <= ATOL_STEP
+    eng.set_option("stack_fault_test", 0)
+
+
+def test_two_engines_on_two_streams_both_match_the_oracle():
+    """Two engines computing on ONE device at the same time from two host threads / two streams - what the fused
+    kernel's residency assumption does not cover.  Each launch fills the whole chip (32 evaluations x 8 M tiles), so
+    the two kernels' workgroups compete for CUs; whatever the dispatcher does (serialise them, or strand both until
+    the spin bound and fall back), BOTH callers must get oracle-correct rolls from their single sample() call."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_layers=3, timesteps=6)
+    models, inputs, refs = [], [], []
+    for i in range(2):
+        p = R.synthetic_params(hp, seed=40 + i)
+        m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+        g = torch.Generator().manual_seed(70 + i)
+        B, Tn = 16, 125
+        wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        noise = torch.randn(6, B, 1, Tn, 88, generator=g)
+        with torch.no_grad():
+            refs.append(R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5))
+        m.engine                                              # create + commit before the threads start
+        m.sample(x, wav, noise=noise)                         # capture the chain graph, front-end done
+        models.append(m)
+        inputs.append((x, wav, noise))
+    torch.cuda.synchronize()
+    results = [[None] * 4 for _ in range(2)]
+    errors = []
+    gate = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                x, wav, noise = inputs[i]
+                for rnd in range(4):
+                    gate.wait(timeout=120)
+                    results[i][rnd] = models[i].sample(x, wav, noise=noise)[0].cpu()
+        except Exception as e:      # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert time.perf_counter() - t0 < 300.0
+    for i in range(2):
+        for rnd in range(4):
+            assert results[i][rnd] is not None
+            d = maxdiff(results[i][rnd], refs[i])
+            assert d <= ATOL_STEP, (i, rnd, d, [m.engine.fallbacks for m in models])
+
+
+# --------------------------------------------------------------------------------------------
+# whole chains at the real BASELINE batches
+# --------------------------------------------------------------------------------------------
+def _thresholded_equal(roll, ref, atol):
+    near = (ref - 0.5).abs() < atol
+    return bool((((roll > 0.5) == (ref > 0.5)) | near).all())
+
+
+def test_config2_real_batch_200_step_chain_vs_oracle():
+    """BASELINE config 2 end to end at its REAL batch: 16 four-second clips, the full k = 9 / C = 512 / 15-layer
+    network, all 200 steps of cfdg_ddpm_x0 (w = 0.5) with identical injected noise - the captured-graph chain the bench
+    line times (fused residual stack, 32 evaluations per step) against the oracle's loop (task/diffusion.py:528-534)."""
+    hp = dict(R.DEFAULT_HP)
+    p = R.synthetic_params(hp, seed=0)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    g = torch.Generator().manual_seed(2016)
+    B, Tn = 16, 125
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    noise = torch.randn(200, B, 1, Tn, 88, generator=g)
+    roll, _ = m.sample(x, wav, noise=noise)
+    m.engine.stack_status()
+    assert m.engine.stack_launches >= 1 and m.engine.fallbacks == 0     # the fused kernel is what ran
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    roll = roll.cpu()
+    d = maxdiff(roll, ref)
+    assert d <= ATOL_STEP, d
+    assert _thresholded_equal(roll, ref, ATOL_STEP)
+
+
+def test_config5_200_step_chain_single_clip_vs_oracle():
+    """BASELINE config 5's network and clip length - k = 15, 640 frames - as a whole 200-step guided chain of one clip
+    (per-phase launches: 16x16-MFMA conv tiles, 160-frame 1x1 blocks, split-K where the launch under-fills)."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(kernel_size=15)
+    p = R.synthetic_params(hp, seed=15)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    g = torch.Generator().manual_seed(5640)
+    Tn = 640
+    wav = 0.1 * torch.randn(1, Tn * 512, generator=g)
+    x = torch.randn(1, 1, Tn, 88, generator=g)
+    noise = torch.randn(200, 1, 1, Tn, 88, generator=g)
+    roll, _ = m.sample(x, wav, noise=noise)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    roll = roll.cpu()
+    d = maxdiff(roll, ref)
+    assert d <= ATOL_STEP, d
+    assert _thresholded_equal(roll, ref, ATOL_STEP)
+
+
+@pytest.mark.parametrize("sampler,B", [("cfdg_ddpm_x0", 4), ("generation_ddpm_x0", 16)])
+def test_reference_shipping_geometry_640_frames_step_vs_oracle(sampler, B):
+    """The geometry the reference itself ships (sampling.py:27: x_T = randn(S, 1, 640, 88); config/sampling.yaml:11:
+    batch_size 4) at k = 9, full width and depth: one reverse step of the guided sampler at batch 4 and of the
+    generation sampler at batch 16 (bench.py --config 6 / 7) against the oracle."""
+    hp = dict(R.DEFAULT_HP)
+    p = R.synthetic_params(hp, seed=0)
+    m = make_model(hp, p, sampler=sampler, w=0.5)
+    g = torch.Generator().manual_seed(640 + B)
+    Tn = 640
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    z = torch.randn(B, 1, Tn, 88, generator=g)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    with torch.no_grad():
+        spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
+        ref = R.reverse_step(p, hp, sch, sampler, x, spec, 137, z, 0.5)
+    out, _ = m.reverse_diffusion(x, wav if sampler != "generation_ddpm_x0" else None, 137, noise=z)
+    d = maxdiff(out.cpu(), ref)
+    assert d <= ATOL_STEP, (sampler, d)
+    # and the same step with the fused kernel forced / forbidden agrees (whatever the cost model picked above)
+    eng = m.engine
+    outs = {}
+    for mode in (0, 2):
+        eng.set_option("fused_stack", mode)
+        outs[mode] = m.reverse_diffusion(x, wav if sampler != "generation_ddpm_x0" else None, 137, noise=z)[0].cpu()
+        assert maxdiff(outs[mode], ref) <= ATOL_STEP, (sampler, mode)
+    eng.set_option("fused_stack", 1)
+
+
+# --------------------------------------------------------------------------------------------
+# trained-weight regime: saturated gates, large pre-activations, large dynamic range
+# --------------------------------------------------------------------------------------------
+def _scaled_params(hp, seed, s_conv, s_out):
+    """Synthetic weights pushed towards what training produces: the dilated convs and conditioner projections scaled by
+    s_conv (pre-activations of the gate reach |u| ~ 10..100: sigmoid and tanh saturate, the hardware exp2 / rcp see
+    their whole range incl. overflow to inf and underflow to 0), the 1x1 output projections by s_out (|h| and the
+    skip sum grow layer by layer to 1e2..1e3: the split-K reduction and the resident LDS tile carry that range)."""
+    p = R.synthetic_params(hp, seed=seed)
+    for i in range(int(hp["residual_layers"])):
+        q = f"residual_layers.{i}."
+        p[q + "dilated_conv.weight"] = p[q + "dilated_conv.weight"] * s_conv
+        p[q + "dilated_conv.bias"] = p[q + "dilated_conv.bias"] * s_conv
+        p[q + "conditioner_projection.weight"] = p[q + "conditioner_projection.weight"] * s_conv
+        p[q + "output_projection.weight"] = p[q + "output_projection.weight"] * s_out
+        p[q + "output_projection.bias"] = p[q + "output_projection.bias"] * s_out
+    return p
+
+
+def _denoise64(p, hp, x, spec, t):
+    """The oracle's network in float64: the reference value both fp32 evaluations are judged against."""
+    p64 = {k: v.double() for k, v in p.items()}
+    table = R.build_embedding(int(hp["timesteps"])).double()
+    with torch.no_grad():
+        return R.denoise(p64, hp, x.double(), spec.double(), t, table)
+
+
+TRAINED_GEOMETRIES = [
+    # (k, B, T, fused_stack option)     which kernels the launch heuristics pick there
+    (9, 16, 125, 1),       # fused stack, 128-frame blocks (the bench geometry: 32 evaluations)
+    (9, 16, 125, 0),       # per-phase: 128-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
+    (9, 8, 125, 1),        # fused stack, 64-frame blocks
+    (9, 1, 125, 1),        # one clip: LDS-staged kernels with split-K x8 and the ticket reduction
+    (15, 2, 640, 0),       # 16x16-MFMA conv tiles (160-frame blocks), 160-frame 1x1
+    (9, 3, 77, 0),         # ragged: 96-frame flavours / small launches
+]
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("scale", [(4.0, 4.0), (16.0, 8.0)])
+def test_trained_regime_battery_vs_float64_oracle(precision, scale):
+    """Kaiming-random weights keep every pre-activation O(1); trained weights do not.  With the weights scaled up the
+    conditional AND unconditional evaluation of the full-width network (5 layers keep the oracle quick) is compared
+    with a FLOAT64 evaluation of the oracle, next to the oracle's own fp32 result: the HIP path (hardware exp2 / rcp in
+    the gate, MFMA summation order, split-K tickets, split-bf16 pieces) must be as accurate as the reference's fp32
+    arithmetic - error <= 6x the fp32 oracle's error + 5e-6 of the output range (the MFMA contracts K = 4608 as one
+    k-ordered FMA chain, the CPU library in blocks: a few times its rounding error is legitimate, a wrong saturation
+    or a lost partial is orders of magnitude) - in every kernel flavour."""
+    s_conv, s_out = scale
+    margins = []
+    for (k, B, Tn, fused) in TRAINED_GEOMETRIES:
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_layers=5, kernel_size=k, timesteps=20)
+        p = _scaled_params(hp, 11 * k + B, s_conv, s_out)
+        m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, precision=precision)
+        m.engine.set_option("fused_stack", fused)
+        g = torch.Generator().manual_seed(1000 * k + Tn + B)
+        wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        t = torch.tensor(13).repeat(B)
+        with torch.no_grad():
+            spec = R.frontend(wav, hp, Tn)
+        for uncond in (False, True):
+            sp = torch.full_like(spec, -1.0) if uncond else spec
+            ref64 = _denoise64(p, hp, x, sp, t)
+            with torch.no_grad():
+                ref32 = R.denoise(p, hp, x, sp, t)
+            got, _ = m(x, wav, t, sampling=uncond)
+            rng = float(ref64.abs().max())
+            e32 = float((ref32.double() - ref64).abs().max())
+            ehip = float((got.cpu().double() - ref64).abs().max())
+            margins.append((k, B, Tn, fused, uncond, rng, e32, ehip))
+            assert math.isfinite(ehip) and ehip <= 6.0 * e32 + 5e-6 * max(rng, 1.0), \
+                (precision, scale, k, B, Tn, fused, uncond, rng, e32, ehip)
+        del m
+    import os
+    log = os.environ.get("DR_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            for (k, B, Tn, fused, uncond, rng, e32, ehip) in margins:
+                f.write(f"trained_regime[{precision},x{s_conv:g}/x{s_out:g},k={k},B={B},T={Tn},fused={fused},uncond={int(uncond)}] "
+                        f"range {rng:.3e} err_fp32_oracle {e32:.3e} err_hip {ehip:.3e}\n")
+
+
+def test_trained_regime_guided_chain_vs_float64_free_oracle():
+    """The same regime through a whole (short) guided chain in the captured graph: saturated gates and a large skip
+    sum through the shared first-layer contraction, the fused stack, tail projections and the update - against the
+    fp32 oracle's loop, tolerance scaled to the roll's range."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_layers=5, timesteps=12)
+    p = _scaled_params(hp, 77, 8.0, 4.0)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    g = torch.Generator().manual_seed(31)
+    B, Tn = 16, 125
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    noise = torch.randn(12, B, 1, Tn, 88, generator=g)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    roll, _ = m.sample(x, wav, noise=noise)
+    rng = max(float(ref.abs().max()), 1.0)
+    d = maxdiff(roll.cpu(), ref)
+    assert d <= ATOL_STEP * rng, (d, rng)
+
+
+# --------------------------------------------------------------------------------------------
+# the FFT kernel directly against torch.stft
+# --------------------------------------------------------------------------------------------
+def test_stft_kernel_directly_against_torch_stft(golden_dir):
+    """The Stockham FFT kernel (reflect pad, Hann window, radix-4 passes in LDS, real split, / ||w||, |.|^2) against
+    torch.stft itself - not through the oracle's front-end wrapper - on the fixture waveforms (noise, silence, a 440 Hz
+    sine, an impulse) and a 20-s clip: the power spectrogram torchaudio's Spectrogram(power=2, normalized=True)
+    returns.  Tolerance: 2e-6 of each clip's largest bin plus fp32 round-off of that bin - the difference between two
+    O(eps log N) FFTs."""
+    import os
+    g = np.load(os.path.join(golden_dir, "frontend.npz"))
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=1, kernel_size=3, timesteps=4)
+    m = make_model(hp, R.synthetic_params(hp, seed=1))
+    eng = m.engine
+    gen = torch.Generator().manual_seed(12)
+    wavs = [torch.from_numpy(np.asarray(g["wav"])).float(),
+            torch.cat([0.1 * torch.randn(1, 327680, generator=gen)]),
+            torch.zeros(1, 4096).index_fill_(1, torch.tensor([1234]), 1.0)]
+    window = torch.hann_window(2048)
+    for wav in wavs:
+        want = torch.stft(wav, n_fft=2048, hop_length=512, win_length=2048, window=window, center=True,
+                          pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+        want = (want / window.pow(2.0).sum().sqrt()).abs().pow(2.0).transpose(1, 2)      # (B, TF, bins)
+        got = eng.stft_power(wav).cpu()
+        assert got.shape == want.shape
+        for b in range(wav.shape[0]):
+            peak = float(want[b].max())
+            d = maxdiff(got[b], want[b])
+            assert d <= 2e-6 * peak + 1e-12, (b, d, peak)
+        if float(wav.abs().max()) == 0.0:
+            assert float(got.abs().max()) == 0.0
+
+
+# --------------------------------------------------------------------------------------------
+# hypothesis-driven shapes
+# --------------------------------------------------------------------------------------------
+def test_hypothesis_shapes_vs_oracle():
+    """Property: for ANY configuration the façade accepts - width (incl. channel counts that need padding to 64), depth,
+    odd kernel size, dilation base / bound, batch, frame count from 1, sampler, guidance weight, step, precision,
+    fused stack on / off / forced - one reverse step equals the oracle's within the fp32 tolerance.  hypothesis picks
+    and SHRINKS the cases (derandomised: the same examples every run); the seeded sweeps of test_gpu_parity.py stay."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    samplers = ["ddpm_x0", "cfdg_ddpm_x0", "generation_ddpm_x0", "inpainting_ddpm_x0", "ddim_x0", "cfdg_ddim_x0",
+                "ddpm", "ddim", "ddim2ddpm"]
+    seen = []
+
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None,
+              suppress_health_check=list(HealthCheck))
+    @given(C=st.sampled_from([4, 32, 64, 68, 96, 128, 192, 256]), layers=st.integers(1, 5),
+           k=st.sampled_from([1, 3, 5, 7, 9, 11, 13, 15]), base=st.integers(1, 3), bound=st.integers(1, 4),
+           B=st.integers(1, 9), Tn=st.integers(1, 330), sampler=st.sampled_from(samplers),
+           w=st.sampled_from([0.0, 0.5, 3.0]), steps=st.integers(1, 9), tq=st.integers(0, 8),
+           bf16=st.booleans(), fused=st.sampled_from([0, 1, 2]))
+    def prop(C, layers, k, base, bound, B, Tn, sampler, w, steps, tq, bf16, fused):
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=C, residual_layers=layers, kernel_size=k, dilation_base=base, dilation_bound=bound,
+                  timesteps=steps)
+        t = tq % steps
+        it = [Tn // 4, max(Tn // 2, Tn // 4 + 1)] if sampler == "inpainting_ddpm_x0" else None
+        p = R.synthetic_params(hp, seed=C * 31 + k)
+        m = make_model(hp, p, sampler=sampler, w=w, inpainting_t=it, precision="bf16x3" if bf16 else "f32")
+        m.engine.set_option("fused_stack", fused)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], steps)
+        g = torch.Generator().manual_seed(B * 1000 + Tn)
+        wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        z = torch.randn(B, 1, Tn, 88, generator=g)
+        with torch.no_grad():
+            spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn, inpainting_t=it)
+            ref = R.reverse_step(p, hp, sch, sampler, x, spec, t, z, w)
+        out, _ = m.reverse_diffusion(x, wav, t, noise=z)
+        d = maxdiff(out.cpu(), ref)
+        seen.append(d)
+        assert d <= ATOL_STEP * max(1.0, float(ref.abs().max())), (d, float(ref.abs().max()))
+        assert m.engine.fallbacks == 0
+
+    prop()
+    assert len(seen) >= 30

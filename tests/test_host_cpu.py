@@ -420,7 +420,17 @@ def test_frontend_tables_carry_the_reference_rounding():
     exact = np.maximum(0, np.minimum((f[:, None] - pts[None, :-2]) / (pts[1:-1] - pts[:-2])[None, :],
                                      (pts[None, 2:] - f[:, None]) / (pts[2:] - pts[1:-1])[None, :]))
     d = np.abs(fb.double().numpy() - exact)
-    assert 5e-6 < d.max() < 1e-4          # fp32 evaluation moves weights by ~2e-5: visible at the parity tolerance
+    # error bound of the fp32 table against the float64 closed form: <= 3e-5 absolute (observed 2.2e-5), i.e. the
+    # restatement IS the published triangle up to fp32 rounding of its own intermediate values - and that rounding
+    # is not negligible (> 5e-6: visible at the parity tolerance, which is why the table is built the reference's way)
+    assert 5e-6 < d.max() <= 3e-5, d.max()
+    # every filter is a triangle: non-negative, peak <= 1, unimodal support, and neighbouring filters overlap
+    fbn = fb.numpy()
+    assert fbn.min() >= 0.0 and fbn.max() <= 1.0 + 1e-6
+    sup = fbn > 0
+    first, last = sup.argmax(0), 1024 - sup[::-1].argmax(0)
+    assert all(sup[first[m]:last[m] + 1, m].all() for m in range(229))
+    assert np.all(np.diff(first) >= 0) and np.all(np.diff(last) >= 0)
     assert int((fb.sum(0) == 0).sum()) == 0     # no empty filter at the released settings
 
 
@@ -496,9 +506,21 @@ def test_bench_workloads_match_the_survey_figures():
     assert bench.flops_per_frame_eval(9) == 157990912 and bench.flops_per_frame_eval(15) == 252362752
     want_tflop = {1: 1.97, 2: 126.4, 3: 63.2, 4: 126.4, 5: 258.4}
     want_gb = {1: 33.6, 2: 252.0, 3: 114.0, 4: 252.0, 5: 363.0}
-    for c, cfg in bench.CONFIGS.items():
+    for c in want_tflop:
+        cfg = bench.CONFIGS[c]
         T = cfg["L"] // 512
         fl = bench.flops_per_frame_eval(cfg["k"]) * cfg["B"] * T * cfg["evals"] * cfg["S"]
         assert abs(fl / 1e12 - want_tflop[c]) / want_tflop[c] < 5e-3, (c, fl)
         assert abs(bench.chain_bytes(cfg, T) / 1e9 - want_gb[c]) / want_gb[c] < 1e-2, (c, bench.chain_bytes(cfg, T))
     assert len(bench.csrc_digest()) == 16
+    # executed work never exceeds the algorithmic count, and differs from it exactly by the shared first-layer
+    # contraction (guided samplers) and the unread residual half of the last 1x1
+    for c, cfg in bench.CONFIGS.items():
+        T = cfg["L"] // 512
+        fl = bench.flops_per_frame_eval(cfg["k"]) * cfg["B"] * T * cfg["evals"] * cfg["S"]
+        fx = bench.executed_flops_per_chain(cfg, T)
+        frames = cfg["B"] * T * cfg["S"]
+        want = fl - (2 * 512 * 1024 * cfg["k"] * frames if cfg["evals"] == 2 else 0) - 2 * 512 * 512 * frames * cfg["evals"]
+        assert fx == want and 0.95 * fl < fx < fl, (c, fx, fl)
+    # the reference's own shipping geometry (sampling.py:27, config/sampling.yaml:11) is a bench workload
+    assert bench.CONFIGS[6]["L"] // 512 == 640 and bench.CONFIGS[6]["B"] == 4 and bench.CONFIGS[7]["L"] // 512 == 640
