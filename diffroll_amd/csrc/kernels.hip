@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     // "not my XCD" and the group keeps the write-through stores that are valid under every placement.
     int wt_store = 1;
     unsigned my_tag = 0;
-    __shared__ unsigned same_xcd_s;
+    unsigned& same_xcd_s = *reinterpret_cast<unsigned*>(Rs + 32 * BN);      // one word behind the resident tile
     if (threadIdx.x == 0) {
         unsigned my_xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
@@ -1273,7 +1273,7 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     const size_t lds = stack_lds_bytes(FL, s.taps, max_dil);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     StackArgs b = s;
-    b.rs_off = (int)(lds - (size_t)32 * BN * 16);
+    b.rs_off = (int)(lds - 16 - (size_t)32 * BN * 16);
     const int NT = s.NB * tps;
     if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;            // the group-per-XCD mapping deals groups round-robin to 8 XCDs
     const dim3 grid((unsigned)(MT * NT));
@@ -1286,7 +1286,7 @@ int stack_tile_frames(int FL) { return FL == 5 ? 160 : 64 * FL; }
 // the conv's double-buffered X tiles + the resident h / skip tile
 size_t stack_lds_bytes(int FL, int taps, int max_dil) {
     const int BN = stack_tile_frames(FL), halo = ((taps - 1) / 2) * max_dil;
-    return (size_t)2 * 8 * (BN + 2 * halo) * 16 + (size_t)32 * BN * 16;
+    return (size_t)2 * 8 * (BN + 2 * halo) * 16 + (size_t)32 * BN * 16 + 16;     // + one flag word (16-byte slot)
 }
 
 // ---------------------------------------------------------------------------------------------
