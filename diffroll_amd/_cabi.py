@@ -37,7 +37,7 @@ EXPORTS = [
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
     "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
-    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power",
+    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds",
 ]
 
 
@@ -53,6 +53,16 @@ class DrConfig(C.Structure):
 
 
 _lib = None
+
+
+def bounds_violations(reset: bool = False):
+    """Checker builds (DR_LIB pointing at a -DDR_BOUNDS library): (code of the first violated check, detail, detail,
+    count); None for a production library."""
+    lib = load_library()
+    out = (C.c_int64 * 4)()
+    if lib.dr_debug_bounds(out, 1 if reset else 0) != 0:
+        return None
+    return tuple(int(v) for v in out)
 
 
 def load_library(path: str = LIB_PATH) -> C.CDLL:
@@ -108,6 +118,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, vp, vp]
     lib.dr_debug_stft_power.restype = C.c_int
     lib.dr_debug_stft_power.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.dr_debug_bounds.restype = C.c_int
+    lib.dr_debug_bounds.argtypes = [C.POINTER(C.c_int64), C.c_int]
     lib.dr_set_spec_norm.restype = C.c_int
     lib.dr_set_spec_norm.argtypes = [vp, C.c_int]
     lib.dr_set_precision.restype = C.c_int

@@ -33,31 +33,59 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+VARIANTS = {
+    # checker builds (tools/checked_build.sh), written next to the production library and selected with DR_LIB=<path>
+    #   bounds: -DDR_BOUNDS - every hand-computed LDS address / in-range buffer offset of the kernels and every tensor
+    #           extent of a launch is checked at run time (dr_debug_bounds reports)
+    #   asan:   the HOST side (engine.hip, comm.hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
+    #           UndefinedBehaviorSanitizer; device code is compiled as usual (-fno-gpu-sanitize)
+    "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
+    "asan": dict(flags=["-O1", "-g", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"],
+                 link=["-fsanitize=address,undefined", "-shared-libsan"]),
+}
+
+
+def variant_path(variant: str) -> str:
+    return os.path.join(LIBDIR, f"libdiffroll_amd_{variant}.so")
+
+
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
+    """variant "" = the production library; "bounds" / "asan" = the checker builds (see VARIANTS)."""
     hipcc = _hipcc()
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, "obj" + ("_" + variant if variant else ""))
     os.makedirs(objdir, exist_ok=True)
+    extra = VARIANTS[variant] if variant else dict(flags=[], link=[])
+    lib = variant_path(variant) if variant else LIB
     objs = []
     relink = force
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra["flags"] + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
             relink = True
         objs.append(o)
-    if relink or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
+    if relink or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + extra["link"] + objs + ["-ldl", "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
+
+
+def asan_runtime() -> str:
+    """The shared ASan runtime a python process must LD_PRELOAD before it dlopens the "asan" variant."""
+    out = subprocess.check_output([_hipcc(), "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    var = ""
+    for a in sys.argv[1:]:
+        if a.startswith("--variant="):
+            var = a.split("=", 1)[1]
+    print(build(force="--force" in sys.argv, variant=var))

@@ -1622,6 +1622,18 @@ int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d
     return DR_OK;
 }
 
+int dr_debug_bounds(int64_t* out4, int reset) {
+    if (!out4) return DR_EINVAL;
+    (void)hipDeviceSynchronize();
+    unsigned long long v[4] = {0, 0, 0, 0};
+    hipError_t he = read_bounds(v);
+    if (he == hipErrorNotSupported) return fail(nullptr, DR_ESTATE, "not a checker build (compile csrc with -DDR_BOUNDS: tools/checked_build.sh)");
+    if (he != hipSuccess) return fail(nullptr, DR_EHIP, "dr_debug_bounds: %s", hipGetErrorString(he));
+    for (int i = 0; i < 4; ++i) out4[i] = (int64_t)v[i];
+    if (reset && reset_bounds() != hipSuccess) return fail(nullptr, DR_EHIP, "dr_debug_bounds: reset failed");
+    return DR_OK;
+}
+
 int dr_set_spec_norm(dr_engine* e, int mode) {
     if (!e) return DR_EINVAL;
     if (mode != DR_NORM_IMAGEWISE && mode != DR_NORM_FRAMEWISE) return fail(e, DR_EINVAL, "unknown normalisation mode %d", mode);

@@ -82,6 +82,7 @@ struct GemmArgs {
     size_t ws_floats, ws_cnt_n;
     int ksplit;              // set by the launcher
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
+    int lds_bytes;           // set by the launcher: dynamic LDS of the launch (read by DR_BOUNDS checker builds only)
     int wt_store;            // fused residual stack only (COH bodies): 1 = the tensors handed to other workgroups are
                              // stored write-through (sc1), 0 = plain stores (every workgroup of the group shares one
                              // XCD's L2, verified at run time)
@@ -90,6 +91,10 @@ struct GemmArgs {
 // gemm_kernel: block tile = 128 packed rows x 64*NI frames (NI in {1, 2}), 512 threads (4 consumer + 4 producer
 // waves); call init_kernels() once per process before any launch.
 hipError_t init_kernels();
+// DR_BOUNDS checker builds: {code of the first violated check, detail, detail, number of violations} / reset;
+// hipErrorNotSupported in production builds
+hipError_t read_bounds(unsigned long long* out4);
+hipError_t reset_bounds();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
 // flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
@@ -125,6 +130,7 @@ struct StackArgs {
     int p0, p1;                               // phases [p0, p1)
     int xcd_n;                                // block -> (M tile, frame tile) mapping, as in gemm_kernel
     int rs_off;                               // set by the launcher: LDS byte offset of the resident h / skip tile
+    int lds_bytes;                            // set by the launcher: dynamic LDS of the launch (DR_BOUNDS checker builds)
     int fault;                                // test hook: barriers wait for one arrival too many (exercises the spin bound)
     int warm;                                 // idle waves warm the L2 with the next phase's weights / conditioner tile
     unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)

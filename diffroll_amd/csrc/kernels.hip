@@ -19,6 +19,7 @@
 // Written for wave64, 512-thread workgroups (4 consumer + 4 producer waves); gfx950 only.
 #include "kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -34,6 +35,75 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   9 = producers do no loads / LDS writes (barriers only)
 #ifndef DR_ABLATE
 #define DR_ABLATE 0
+#endif
+
+// DR_BOUNDS (compile-time, checker builds only: tools/checked_build.sh): every hand-computed LDS address and every
+// in-range buffer offset of the GEMM bodies and the fused kernel is compared with the region it must stay in; the
+// first violation is recorded in g_bounds (code, two details) and counted - nothing traps, the run completes and
+// dr_debug_bounds reports.  (The LDS-DMA X-tile loads and pw_body's activation loads go out of range ON PURPOSE -
+// the hardware bounds check of the buffer descriptor is the conv's zero padding - and are not checked.)
+#ifdef DR_BOUNDS
+__device__ unsigned long long g_bounds[4];            // {code of the first violation, detail, detail, violations}
+DR_DEVINL void bounds_fail(unsigned code, long a, long b) {
+    if (atomicCAS(&g_bounds[0], 0ull, (unsigned long long)code) == 0ull) { g_bounds[1] = (unsigned long long)a; g_bounds[2] = (unsigned long long)b; }
+    atomicAdd(&g_bounds[3], 1ull);
+}
+DR_DEVINL unsigned lds_off(const void* p) {          // byte address inside the workgroup's LDS allocation
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+#define DR_CHECK(cond, code, a, b) do { if (!(cond)) bounds_fail((code), (long)(a), (long)(b)); } while (0)
+// a 16-byte LDS access at p must lie inside [lo, hi)
+#define DR_CHECK_LDS(p, lo, hi, code) do { const unsigned o_ = lds_off(p); if (o_ < (unsigned)(lo) || o_ + 16u > (unsigned)(hi)) bounds_fail((code), o_, (hi)); } while (0)
+// host side of the checker: what a launch will touch of each tensor argument (base + extent of the buffer descriptors /
+// flat accesses built from GemmArgs) against the device allocation the pointer lives in (hipMemGetAddressRange)
+static unsigned long long g_host_violations = 0;
+static void host_extent(const void* p, size_t bytes, const char* what, const char* kernel) {
+    if (!p || !bytes) return;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)p) != hipSuccess) { (void)hipGetLastError(); return; }   // not a device allocation
+    if ((const char*)p < (const char*)base || (const char*)p + bytes > (const char*)base + size) {
+        ++g_host_violations;
+        fprintf(stderr, "[DR_BOUNDS] %s: %s needs %zu bytes at +%zd of a %zu-byte allocation\n", kernel, what, bytes,
+                (ssize_t)((const char*)p - (const char*)base), size);
+    }
+}
+static void check_gemm_extents(const GemmArgs& a, int epi, int prec, const char* kernel) {
+    const size_t slab = prec ? 24576 : 16384;
+    const int mts = a.mt0 + a.MT;
+    host_extent(a.Wp, (size_t)mts * a.kchunks * a.taps * slab, "packed weights", kernel);
+    host_extent(a.bias, (size_t)mts * 128 * 4, "bias", kernel);
+    if (epi == EPI_GATE) host_extent(a.bias2, (size_t)mts * 128 * 4, "bias2", kernel);
+    const long nbx = a.x_bmod ? (a.NB < a.x_bmod ? a.NB : a.x_bmod) : a.NB;
+    if (!prec) host_extent(a.X, (size_t)((nbx - 1) * a.x_bs + (long)(a.x_planes - 1) * a.x_ps + (long)(a.T - 1) * a.x_fs + 4) * 4, "X", kernel);
+    const long nby = a.NB + (a.dual > 0 ? a.dual : 0);
+    const long planes = (a.y_rows + 3) / 4;
+    if (!(a.out_s3 & 1)) host_extent(a.Y, (size_t)((nby - 1) * a.y_bs + (planes - 1) * a.y_ps + (long)(a.T - 1) * a.y_fs + 4) * 4, "Y", kernel);
+    if (a.Y2 && !(a.out_s3 & 2)) host_extent(a.Y2, (size_t)((nby - 1) * a.y2_bs + (planes - 1) * a.y_ps + (long)(a.T - 1) * a.y_fs + 4) * 4, "Y2", kernel);
+    if (epi == EPI_GATE && a.cond) host_extent(a.cond, (size_t)((long)(a.n_cond > 1 ? a.n_cond - 1 : 0) * a.c_bs + (long)mts * 128 * a.T) * 4, "conditioner", kernel);
+    if (epi == EPI_GATE && a.cond2) host_extent(a.cond2, (size_t)mts * 128 * a.T * 4, "conditioner (shared)", kernel);
+    if (epi == EPI_RES_SKIP && a.skip && mts * 128 > a.y_rows)
+        host_extent(a.skip, (size_t)((long)(a.NB - 1) * a.s_bs + (long)(mts * 128 - a.y_rows) * a.T) * 4, "skip", kernel);
+    if (a.ws) host_extent(a.ws, a.ws_floats * 4, "split-K workspace", kernel);
+    if (a.ws_cnt) host_extent(a.ws_cnt, a.ws_cnt_n * 4, "split-K counters", kernel);
+}
+hipError_t read_bounds(unsigned long long* out4) {
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_bounds), 4 * sizeof(unsigned long long));
+    if (e == hipSuccess && g_host_violations) { if (!out4[0]) out4[0] = 999; out4[3] += g_host_violations; }
+    return e;
+}
+hipError_t reset_bounds() {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    g_host_violations = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), z, sizeof z);
+}
+#define DR_CHECK_EXTENTS(a, epi, prec, kernel) check_gemm_extents((a), (epi), (prec), (kernel))
+#else
+#define DR_CHECK_EXTENTS(a, epi, prec, kernel) do {} while (0)
+#define DR_CHECK(cond, code, a, b) do {} while (0)
+#define DR_CHECK_LDS(p, lo, hi, code) do {} while (0)
+hipError_t read_bounds(unsigned long long*) { return hipErrorNotSupported; }
+hipError_t reset_bounds() { return hipErrorNotSupported; }
 #endif
 
 struct A8 { float4 v[8]; };                          // A fragments of one K step: [group g][row tile mi]
@@ -204,6 +274,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // [32 planes][BN frames] float4, DMA'd by the producers at kernel start and read by the epilogue.
     // (Holding it in 64 prefetch VGPRs instead cost the compiler the B-fragment software pipelining.)
     float4* Rs = Xs + 2 * XP * FW;
+#ifdef DR_BOUNDS
+    const unsigned xs0 = lds_off(Xs), xs1 = xs0 + 2u * XP * FW * 16u, rs1 = xs1 + (EPI == EPI_RES_SKIP ? 32u * BN * 16u : 0u);
+    if (tid == 0 && !COH) DR_CHECK(rs1 <= (unsigned)a.lds_bytes, 100, rs1, a.lds_bytes);      // the regions fit the launch's LDS
+#endif
 
     // (mt, nt, ks) = this block's M tile, frame tile and K split: chosen by the caller (gemm_kernel below)
     const int tps = (a.T + BN - 1) / BN;
@@ -246,6 +320,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
                 float4* dst = Xs + (((chunk - c0) & 1) * XP + pl) * FW + seg * 64;
+                if (f < FW) DR_CHECK_LDS(dst + lane, xs0, xs1, 101);
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, COH ? 16 : 0);
             }
         };
@@ -260,6 +335,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                     : a.skip + (long)b * a.s_bs + (long)((row0 - a.y_rows) >> 2) * a.T * 4;
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rrecs, 0x00020000);
                 const int voff = (t0 + seg * 64 + lane) * 16;
+                DR_CHECK_LDS(Rs + pl * BN + seg * 64 + lane, xs1, rs1, 102);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, voff, 0, 0, 0);
             }
         }
@@ -311,6 +387,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #if DR_ABLATE == 2          // measurement build: always the same slab (L1-hot A loads)
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, gp * 4096, 0);
 #else
+                DR_CHECK(slab >= 0 && wvo + slab * 24576 + gp * 4096 + 16 <= NS * 24576, 103, slab, NS);
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 24576 + gp * 4096, 0);
 #endif
                 o.v[gp * 2] = make_uint4(u.x, u.y, u.z, u.w);
@@ -336,7 +413,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #pragma unroll
             for (int pz = 0; pz < 3; ++pz)
 #pragma unroll
-                for (int ni = 0; ni < NW; ++ni) o.v[pz][ni] = Xb[(g * 6 + pz * 2) * FW + ni * 32];
+                for (int ni = 0; ni < NW; ++ni) {
+                    DR_CHECK_LDS(Xb + (g * 6 + pz * 2) * FW + ni * 32, xs0, xs1, 104);
+                    o.v[pz][ni] = Xb[(g * 6 + pz * 2) * FW + ni * 32];
+                }
             return o;
         };
         // six piece products per accumulator, smallest terms first; consecutive MFMAs go to different
@@ -409,6 +489,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         A8 o;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 105, slab, NS);
             const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);
             o.v[g * 2] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
         }
@@ -429,7 +510,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     auto rd = [&](const float4* Xb, int g) -> BF {
         BF o;
 #pragma unroll
-        for (int ni = 0; ni < NW; ++ni) o.v[ni] = Xb[g * 2 * FW + ni * 32];
+        for (int ni = 0; ni < NW; ++ni) {
+            DR_CHECK_LDS(Xb + g * 2 * FW + ni * 32, xs0, xs1, 106);
+            o.v[ni] = Xb[g * 2 * FW + ni * 32];
+        }
         return o;
     };
     // 8 channels of K for every frame tile: consecutive MFMAs go to different accumulators (the pinned schedule
@@ -529,10 +613,12 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             for (int q = 0; q < 4; ++q) {
                 const u32x4 v = {__float_as_uint(acc[0][ni][4 * q]), __float_as_uint(acc[0][ni][4 * q + 1]),
                                  __float_as_uint(acc[0][ni][4 * q + 2]), __float_as_uint(acc[0][ni][4 * q + 3])};
+                DR_CHECK((size_t)(base + ks * sstride + (ni * 4 + q) * 1024) + 16 <= a.ws_floats * 4, 107, base + ks * sstride, a.ws_floats);
                 __builtin_amdgcn_raw_buffer_store_b128(v, wsr, base + ks * sstride + (ni * 4 + q) * 1024, 0, WSCOH);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // partials are out before the ticket is drawn
         unsigned ticket = 0;
+        DR_CHECK((size_t)(tile * 4 + wave) < a.ws_cnt_n, 108, tile * 4 + wave, a.ws_cnt_n);
         if (lane == 0) ticket = __hip_atomic_fetch_add(a.ws_cnt + tile * 4 + wave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ticket = __builtin_amdgcn_readfirstlane(ticket);
         if (ticket != (unsigned)(a.ksplit - 1)) return;
@@ -550,8 +636,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int i = 0; i < WQ; ++i)
+                for (int i = 0; i < WQ; ++i) {
+                    DR_CHECK((size_t)(base + (sp0 + u) * sstride + i * 1024) + 16 <= a.ws_floats * 4, 109, base + (sp0 + u) * sstride, a.ws_floats);
                     v[u][i] = __builtin_amdgcn_raw_buffer_load_b128(wsr, base + (sp0 + u) * sstride + i * 1024, 0, WSCOH);
+                }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -609,8 +697,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
     #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q) {
+                        DR_CHECK_LDS(Rs + (wr * (WROWS / 4) + mi * 8 + 2 * q + hi) * BN + wc * WFR + ni * 32 + r, xs1, rs1, 110);
                         eop[mi][ni][q] = Rs[(wr * (WROWS / 4) + mi * 8 + 2 * q + hi) * BN + wc * WFR + ni * 32 + r];
+                    }
             }
             if constexpr (EPI == EPI_GATE) {
                 // conditioner quads of this frame column: one unconditional batch (unconditional samples read
@@ -819,7 +909,10 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
     auto load_a = [&](int slab) -> AF {
         AF o;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) o.v[g] = asf4(__builtin_amdgcn_raw_buffer_load_b128(wr, wvo, slab * 16384 + g * 4096, 0));
+        for (int g = 0; g < 4; ++g) {
+            DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 120, slab, NS);
+            o.v[g] = asf4(__builtin_amdgcn_raw_buffer_load_b128(wr, wvo, slab * 16384 + g * 4096, 0));
+        }
         return o;
     };
     auto load_b = [&](int slab) -> BF {
@@ -922,6 +1015,9 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
             for (int e = 0; e < 4; ++e) v[e] = acc[ni][4 * q + e];
             float4* rs = nullptr;                                                   // this quad in the LDS tile (RLDS)
             if constexpr (RLDS) rs = Rs + (wave * 8 + 2 * q + hi) * BN + foff + ni * 32 + r;
+#ifdef DR_BOUNDS
+            if constexpr (RLDS) DR_CHECK_LDS(rs, lds_off(Rs), lds_off(Rs) + 32u * BN * 16u, 121);
+#endif
             f4arr(ebias[q], bb);
             if constexpr (RLDS) f4arr(*rs, pv);
             else f4arr(eop[ni][q], pv);
@@ -982,6 +1078,7 @@ static hipError_t launch_pw_t(const GemmArgs& a, hipStream_t s) {
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
     static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
     if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
+    DR_CHECK_EXTENTS(b, EPI_RES_SKIP, 0, "pw_kernel");
     hipLaunchKernelGGL((pw_kernel<NW>), dim3((unsigned)(a.MT * NT)), dim3(256), 0, s, b);
     return hipGetLastError();
 }
@@ -1103,6 +1200,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     // the per-phase kernels.  (Written by an EARLIER kernel of the stream: visible across the kernel boundary.)
     // (the flag is requested here and tested after the resident tile's loads are issued: its latency hides there)
     const unsigned pending_timeout = __hip_atomic_load(s.derr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DR_CHECK(grp >= 0 && grp < 512 && (long)grp * gsize + member < 1024, 130, grp, member);       // counters / tag words
     unsigned* ctr = s.bar + 4 * grp;                      // {arrivals, departures, generation, -}
     const long act_bs = (long)s.Cp * s.T;
     const int P = s.Cp >> 2;
@@ -1131,6 +1229,10 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             bool is_res;
             const float* src = tile_plane(pl, is_res);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)s.T * 16u, 0x00020000);
+#ifdef DR_BOUNDS
+            if (seg * 64 + lane < BN) DR_CHECK_LDS(Rs + pl * BN + seg * 64 + lane, s.rs_off, s.rs_off + 32 * BN * 16, 131);
+            if (threadIdx.x == 0 && i == 0) DR_CHECK(s.rs_off + 32 * BN * 16 + 16 <= s.lds_bytes && lds_off(smem) == 0u, 132, s.rs_off, s.lds_bytes);
+#endif
             if (seg * 64 + lane < BN)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0_ + seg * 64 + lane) * 16, 0, 0, 0);
         }
@@ -1164,6 +1266,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[p - s.p0] = clock64();
         GemmArgs a{};
         a.d2 = s.zero;
+        a.lds_bytes = s.lds_bytes;
         a.wt_store = wt_store;
         a.MT = MT; a.NB = s.NB; a.T = s.T; a.alpha = 1.f; a.ksplit = 1;
         a.x_bs = act_bs; a.x_ps = (long)s.T * 4; a.x_fs = 4; a.x_planes = P; a.kchunks = s.Cp >> 5;
@@ -1250,6 +1353,9 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             bool is_res;
             float* dst = tile_plane(pl, is_res);
             const int t = t0_ + seg * 64 + lane;
+#ifdef DR_BOUNDS
+            if (seg * 64 + lane < BN) DR_CHECK_LDS(Rs + pl * BN + seg * 64 + lane, s.rs_off, s.rs_off + 32 * BN * 16, 133);
+#endif
             if (seg * 64 + lane < BN && t < s.T && (!is_res || s.p1 < 2 * s.L))
                 *reinterpret_cast<float4*>(dst + (long)t * 4) = Rs[pl * BN + seg * 64 + lane];
         }
@@ -1274,8 +1380,23 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     StackArgs b = s;
     b.rs_off = (int)(lds - 16 - (size_t)32 * BN * 16);
+    b.lds_bytes = (int)lds;
     const int NT = s.NB * tps;
     if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;            // the group-per-XCD mapping deals groups round-robin to 8 XCDs
+#ifdef DR_BOUNDS
+    for (int l = 0; l < s.L; ++l) {
+        GemmArgs g{};
+        g.MT = MT; g.NB = s.NB; g.T = s.T; g.taps = s.taps; g.kchunks = s.Cp >> 5; g.y_rows = s.Cp;
+        g.x_bs = g.y_bs = g.y2_bs = g.s_bs = (long)s.Cp * s.T; g.x_ps = g.y_ps = (long)s.T * 4; g.x_fs = g.y_fs = 4; g.x_planes = s.Cp >> 2;
+        g.Wp = s.layer[l].conv_w; g.bias = s.layer[l].conv_b; g.bias2 = s.layer[l].conv_b2; g.X = s.hd; g.Y = s.g;
+        g.cond = s.layer[l].cond; g.cond2 = s.layer[l].cond2; g.c_bs = s.c_bs; g.n_cond = s.n_cond;
+        check_gemm_extents(g, EPI_GATE, 0, "stack_kernel (conv phase)");
+        g.taps = 1; g.Wp = s.layer[l].out_w; g.bias = s.layer[l].out_b; g.X = s.g; g.Y = s.h; g.Y2 = s.hd; g.skip = s.skip;
+        check_gemm_extents(g, EPI_RES_SKIP, 0, "stack_kernel (1x1 phase)");
+    }
+    host_extent(s.bar, (size_t)4 * 512 * 4, "group counters", "stack_kernel");
+    host_extent(s.xid, (size_t)1024 * 4, "tag words", "stack_kernel");
+#endif
     const dim3 grid((unsigned)(MT * NT));
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
@@ -1317,6 +1438,10 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
     const int FW = BN + 2 * halo;
     float4* Xs = reinterpret_cast<float4*>(smem);   // [2][XP][FW]
     float4* Rs = Xs + 2 * XP * FW;                  // EPI_RES_SKIP: [32 planes][BN]
+#ifdef DR_BOUNDS
+    const unsigned xs0 = lds_off(Xs), xs1 = xs0 + 2u * XP * FW * 16u, rs1 = xs1 + (EPI == EPI_RES_SKIP ? 32u * BN * 16u : 0u);
+    if (tid == 0 && !COH) DR_CHECK(rs1 <= (unsigned)a.lds_bytes, 140, rs1, a.lds_bytes);
+#endif
 
     const int tps = (a.T + BN - 1) / BN;
     const int b = nt / tps;
@@ -1341,6 +1466,7 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;
                 float4* dst = Xs + ((chunk & 1) * XP + pl) * FW + seg * 64;
+                if (f < FW) DR_CHECK_LDS(dst + lane, xs0, xs1, 141);
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, COH ? 16 : 0);
             }
         };
@@ -1355,6 +1481,7 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
                     : a.skip + (long)b * a.s_bs + (long)((row0 - a.y_rows) >> 2) * a.T * 4;
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rrecs, 0x00020000);
                 const int f = seg * 64 + lane;
+                if (f < BN) DR_CHECK_LDS(Rs + pl * BN + seg * 64 + lane, xs1, rs1, 142);
                 if (f < BN)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, (t0 + f) * 16, 0, 0, 0);
             }
@@ -1390,6 +1517,7 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
+                DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 8192 + rt * 256 + 16 <= NS * 16384, 143, slab, NS);
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 8192 + rt * 256, 0);
                 o.v[g * RT + rt] = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
             }
@@ -1410,7 +1538,10 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
     auto rd = [&](const float4* Xb, int g) -> BF {
         BF o;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) o.v[ct] = Xb[g * 4 * FW + ct * 16];
+        for (int ct = 0; ct < CT; ++ct) {
+            DR_CHECK_LDS(Xb + g * 4 * FW + ct * 16, xs0, xs1, 144);
+            o.v[ct] = Xb[g * 4 * FW + ct * 16];
+        }
         return o;
     };
     auto mma = [&](const float4 af, const BF& bf, int rt) {
@@ -1509,8 +1640,10 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
         } else {
             float4 pv4[RT];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int rt = 0; rt < RT; ++rt) {
+                DR_CHECK_LDS(Rs + ((wr * WROWS + rt * 16) / 4 + kq) * BN + wc * WFR + ct * 16 + li, xs1, rs1, 145);
                 pv4[rt] = Rs[((wr * WROWS + rt * 16) / 4 + kq) * BN + wc * WFR + ct * 16 + li];
+            }
             if (t >= a.T) continue;
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
@@ -1569,6 +1702,8 @@ static hipError_t launch_gemm16_t(const GemmArgs& a, hipStream_t s) {
     GemmArgs b = a;
     const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    b.lds_bytes = (int)lds;
+    DR_CHECK_EXTENTS(b, EPI, 0, "gemm16_kernel");
     hipLaunchKernelGGL((gemm16_kernel<NJ, KS, EPI>), dim3((unsigned)(a.MT * NT)), dim3(512), lds, s, b);
     return hipGetLastError();
 }
@@ -1622,12 +1757,14 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
                (size_t)tiles * (b.ksplit * 2) * 128 * BN <= a.ws_floats && (size_t)tiles * 4 <= a.ws_cnt_n)
             b.ksplit *= 2;
     }
+    b.lds_bytes = (int)lds;
     const dim3 grid((unsigned)(a.MT * NT * b.ksplit));
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
     const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
     static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
     if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
+    DR_CHECK_EXTENTS(b, EPI, PREC, "gemm_kernel");
     hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
 }

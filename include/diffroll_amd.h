@@ -260,6 +260,13 @@ int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, cons
  * hold the FFT kernel to torch.stft directly.  n_fft must be a power of two.  Synchronises `stream`. */
 int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d_power_out, void* stream);
 
+/* Checker builds only (csrc compiled with -DDR_BOUNDS, tools/checked_build.sh): every hand-computed LDS address and
+ * in-range buffer offset of the GEMM kernels and of the fused residual-stack kernel is compared at run time with the
+ * region it must stay inside, and every tensor extent a launch will touch with the device allocation it lives in.
+ * out4 = {code of the first violated check (0 = none), two details, number of violations} since the last reset.
+ * A production build returns DR_ESTATE.  Synchronises the device. */
+int dr_debug_bounds(int64_t* out4, int reset);
+
 /* Spectrogram normalisation of the following dr_frontend calls: the mode of Normalization(0, 1, norm_args[2])
  * (model/diffwave.py:632, model/utils.py:10-32) - min-max per clip ("imagewise", the default and the released
  * configs) or per frame over the frequency bins ("framewise"). */

@@ -24,3 +24,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Checker runs (tools/checked_build.sh: DR_LIB points at the -DDR_BOUNDS library): the session fails if any LDS /
+    buffer-offset / tensor-extent check fired in this process (child processes report their own: tests/fused_cases.py)."""
+    import os
+    if not os.environ.get("DR_BOUNDS_REPORT"):
+        return
+    from diffroll_amd import _cabi
+    if _cabi._lib is None:
+        return
+    v = _cabi.bounds_violations()
+    print(f"\n[DR_BOUNDS] {'production library (no checks)' if v is None else 'violations (code, detail, detail, count) = ' + str(v)}")
+    if v is not None and v[3] != 0:
+        session.exitstatus = 1

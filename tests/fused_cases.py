@@ -117,6 +117,11 @@ def main():
             out.append({"case": [label], "vs_oracle": 0.0,
                         "runs": [{"xcd": 1, "timed_out": flag, "launches": eng.stack_launches - n0, "kernel": "stack_kernel<1>",
                                   "equal": bool(torch.equal(got, ref)), "maxdiff": float((got - ref).abs().max())}]})
+    from diffroll_amd import _cabi
+    v = _cabi.bounds_violations()          # checker builds (tools/checked_build.sh): this process's own record
+    if v is not None:
+        out.append({"case": ["DR_BOUNDS"], "vs_oracle": 0.0, "bounds": list(v),
+                    "runs": [{"xcd": 1, "timed_out": 0, "launches": 1, "kernel": f"stack_kernel<{ni}>", "equal": v[3] == 0, "maxdiff": float(v[3])}]})
     print("FUSED_CASES " + json.dumps(out), flush=True)
 
 
