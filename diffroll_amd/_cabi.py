@@ -37,7 +37,7 @@ EXPORTS = [
     "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
     "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
-    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds",
+    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds", "dr_tail_launches",
 ]
 
 
@@ -109,6 +109,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                                       C.POINTER(C.c_int32), vp]
     lib.dr_stack_fallbacks.restype = C.c_int
     lib.dr_stack_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.dr_tail_launches.restype = C.c_int
+    lib.dr_tail_launches.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.dr_frame_counts.restype = C.c_int
     lib.dr_frame_counts.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_int64), vp]
     lib.dr_note_runs.restype = C.c_int

@@ -120,6 +120,13 @@ struct dr_engine {
     volatile unsigned* stack_err_host = nullptr;
     unsigned* stack_derr = nullptr;     // the same flag in device memory (what the kernels poll / test at launch start)
     unsigned* stack_xid = nullptr;      // [1024] (generation, XCC id) tags published by the blocks of the last launch
+    unsigned* stack_pbar = nullptr;     // [STACK_GROUPS][4] pair counters of the shared phase 0 (classifier-free guidance)
+    unsigned* tail_bar = nullptr;       // group / pair counters of the tail kernel (own arrays, same protocol)
+    unsigned* tail_pbar = nullptr;
+    int opt_tail = 1;                   // fused step: layer 0's shared conv inside the stack launch + the tail kernel
+    int64_t tail_launches = 0;
+    float* xalt = nullptr;              // the tail kernel writes x_{t-1} here (it must not update x_t in place: other
+                                        // blocks still read it); the chain ping-pongs between this and its roll buffer
     int64_t stack_fallbacks = 0;        // time-outs detected by dr_finish: each one switched this engine to per-phase launches
     float* xsave = nullptr;             // dr_sample_checked: copy of x_T, so that a timed-out chain can be re-run
     size_t xsave_cap = 0;
@@ -464,6 +471,7 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     if ((rc = dev_alloc(e, &e->tmp, act))) return rc;
     if ((rc = dev_alloc(e, &e->x0buf, (size_t)nb * T * 88))) return rc;
     if ((rc = dev_alloc(e, &e->xwork, (size_t)nb * T * 88))) return rc;
+    if ((rc = dev_alloc(e, &e->xalt, (size_t)nb * T * 88))) return rc;
     if ((rc = dev_alloc(e, &e->cond_dummy, (size_t)2 * e->Cp * T))) return rc;
     e->ws_NB = nb;
     e->ws_T = T;
@@ -474,10 +482,23 @@ int ensure_workspace(dr_engine* e, int NB, int T) {
     return DR_OK;
 }
 
+// What run_step offers run_network so that a whole reverse step becomes TWO launches (the residual stack incl. layer 0's
+// shared contraction + the tail kernel: skip / output projection, update, next input projection) where the fused
+// kernel applies; run_network reports back what it took.
+struct TailPlan {
+    UpdateArgs u{};            // this step's update (x = x_t, read only by the tail kernel)
+    float* x_out = nullptr;    // where the tail kernel writes x_{t-1}
+    int u_B = 0;               // rolls
+    int next_t = -1;           // >= 0: the chain continues with step next_t (its input projection joins the tail)
+    bool skip_inproj = false;  // h / hd of THIS step (and, guided, layer 0's g) were written by the previous step's tail
+    bool done = false;         // out: the tail kernel ran (update included, result in x_out)
+    bool inproj_done = false;  // out: ... and it wrote the next step's h / hd (and layer 0's g for a guided pair)
+};
+
 // One network evaluation for NB samples (first n_cond conditional) at step t.
 //   xin (B,T,88) rows are used modulo bmod (classifier-free batching: 2B evaluations of B inputs).
 int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, int T, int t, float* x0_out,
-                hipStream_t st, bool zero_spec = false, const int* tsel = nullptr) {
+                hipStream_t st, bool zero_spec = false, const int* tsel = nullptr, TailPlan* tail = nullptr) {
     // tsel (device, NB ints): per-sample diffusion steps (forward() with a (B,) step tensor); else step t for all
     const int Cp = e->Cp, P = Cp / 4, L = e->L;
     const int prec = e->prec;
@@ -487,26 +508,12 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         a.X = X; a.x_bs = s3_bs; a.x_piece = (long)(Cp / 8) * T * 4; a.x_ps = (long)T * 4; a.x_fs = 4;
         a.x_planes = Cp / 8; a.kchunks = Cp / 32;
     };
-    // input projection + relu (model/diffwave.py:667-668)
-    {
-        GemmArgs a{};
-        a.Wp = e->in_w; a.bias = e->in_b; a.MT = (Cp + 127) / 128;
-        a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
-        a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
-        p4_out(a, e->h, P, T, Cp);
-        // hd = h + d_0 (model/diffwave.py:138-139), fp32 P4 or split-bf16 for the first dilated conv
-        a.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
-        a.tsel = tsel; a.d2_ts = (long)L * Cp;
-        if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
-        else { a.Y2 = e->hd; a.y2_bs = act_bs; }
-        allow_splitk(e, a);
-        HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
-    }
     // ---- fused residual stack: the layers as ONE persistent launch when all its blocks are resident at once ----
     // (exact fp32 only; the first layer's conv stays a launch of its own under classifier-free guidance, where it
     // is contracted once per (conditional, unconditional) pair)
     int stack_from = -1;                   // first phase run by the fused kernel (-1: none)
     int stack_ni = 0, stack_chunks = 1;    // flavour, and how many sample chunks the evaluation is launched in
+    bool fused_step = false;
     if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
@@ -552,7 +559,28 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         if (stack_ni && e->opt_stack != 2 && best > per_phase_cost()) stack_ni = 0;
         const bool dual0 = (bmod > 0 && NB == 2 * bmod && n_cond == bmod);
         if (stack_ni) stack_from = dual0 ? 1 : 0;
+        // fused step (option "fused_tail"): everything behind the stack launch - skip / output projection, update, and
+        // for a chain the next step's input projection and (guided) shared first-layer conv - is one tail launch,
+        // when the evaluation is ONE fused launch of the 32x32-MFMA flavours
+        fused_step = stack_ni && stack_ni != 5 && stack_chunks == 1 && e->opt_tail && !tsel;
     }
+    const bool use_tail = fused_step && tail != nullptr;
+    // input projection + relu (model/diffwave.py:667-668) - unless the previous step's tail kernel already wrote h / hd
+    if (!(use_tail && tail->skip_inproj)) {
+        GemmArgs a{};
+        a.Wp = e->in_w; a.bias = e->in_b; a.MT = (Cp + 127) / 128;
+        a.X = xin; a.x_bs = (long)T * 88; a.x_ps = 4; a.x_fs = 88; a.x_planes = 22; a.x_bmod = bmod;
+        a.kchunks = 3; a.NB = NB; a.T = T; a.taps = 1; a.dil = 1; a.alpha = 1.f;
+        p4_out(a, e->h, P, T, Cp);
+        // hd = h + d_0 (model/diffwave.py:138-139), fp32 P4 or split-bf16 for the first dilated conv
+        a.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
+        a.tsel = tsel; a.d2_ts = (long)L * Cp;
+        if (prec) { a.Y2 = e->hd3; a.y2_bs = s3_bs; a.out_s3 = 2; }
+        else { a.Y2 = e->hd; a.y2_bs = act_bs; }
+        allow_splitk(e, a);
+        HIPCHK(e, launch_gemm(a, EPI_RELU, pick_ni(a.MT, NB, T, 1, 1), st));
+    }
+
     auto launch_stack_range = [&](int p0, int p1) -> int {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
@@ -612,7 +640,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     }
     for (int l = 0; l < L && stack_from != 0; ++l) {
         const LayerW& w = e->layers[l];
-        {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
+        // (layer 0's shared conv of a guided step was already done by the previous step's tail kernel)
+        if (!(l == 0 && stack_from == 1 && use_tail && tail->skip_inproj)) {   // dilated conv of (h + d_l) + conditioner, gate (model/diffwave.py:138-147)
             GemmArgs a = p4_gemm(prec ? w.conv_w3 : w.conv_w, w.conv_b, Cp / 64, e->hd, P, NB, T);
             if (prec) s3_in(a, e->hd3);
             a.bias2 = zero_spec ? w.conv_b_z : w.conv_b_u;   // samples >= n_cond: spec == 0 or spec == -1
@@ -675,6 +704,38 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, tile, st, prec));
         }
     }
+    if (use_tail) {
+        // the rest of the step in one launch: skip projection, output projection, combine + update, next input projection
+        TailArgs ta{};
+        ta.NB = NB; ta.T = T; ta.Cp = Cp; ta.BN = stack_tile_frames(stack_ni);
+        ta.dual = (bmod > 0 && NB == 2 * bmod) ? bmod : 0;
+        ta.u_B = tail->u_B;
+        ta.xcd_n = e->opt_stack_xcd; ta.fault = e->opt_stack_fault;
+        ta.alpha = (float)(1.0 / std::sqrt((double)L));
+        ta.skip = e->skip; ta.tmp = e->tmp; ta.x0 = x0_out;
+        ta.skip_w = e->skip_w; ta.skip_b = e->skip_b; ta.outp_w = e->outp_w; ta.outp_b = e->outp_b; ta.zero = zero_vec();
+        ta.u = tail->u; ta.x_out = tail->x_out;
+        if (tail->next_t >= 0) {
+            ta.in_w = e->in_w; ta.in_b = e->in_b; ta.d2_next = e->d_dtab + (size_t)tail->next_t * L * Cp;
+            ta.h = e->h; ta.hd = e->hd;
+            if (ta.dual > 0 && n_cond == bmod) {        // the next step's shared first-layer conv (as the dual launch above)
+                const LayerW& w0 = e->layers[0];
+                ta.conv_w = w0.conv_w; ta.conv_b = w0.conv_b;
+                ta.conv_b2 = zero_spec ? w0.conv_b_z : w0.conv_b_u;
+                if (e->cond_tr && !zero_spec) { ta.cond2 = e->cond_tr; ta.conv_b2 = w0.conv_b; }
+                ta.cond = e->cond ? e->cond : e->cond_dummy;
+                ta.c_bs = (long)2 * Cp * T;
+                ta.taps = e->K; ta.dil = w0.dil;
+                ta.g = e->g;
+            }
+        }
+        ta.bar = e->tail_bar; ta.pbar = e->tail_pbar; ta.err = e->stack_err; ta.derr = e->stack_derr;
+        HIPCHK(e, launch_tail(ta, st));
+        e->tail_launches += 1;
+        tail->done = true;
+        tail->inproj_done = tail->next_t >= 0;
+        return DR_OK;
+    }
     {   // skip / sqrt(L) -> skip_projection -> relu (model/diffwave.py:682-684)
         GemmArgs a = p4_gemm(e->skip_w, e->skip_b, (Cp + 127) / 128, e->skip, P, NB, T);
         a.alpha = (float)(1.0 / std::sqrt((double)L));
@@ -711,16 +772,17 @@ int sampler_shape(int sampler, int B, int& NB, int& n_cond) {
     return sampler_shape(sampler, B, NB, n_cond, fam, z);
 }
 
+// One reverse step.  The result is written in place on x - or, when the fused step ran (tail kernel), into e->xalt:
+// *result tells which; chain (optional) carries "h / hd of this step are already there" from step to step.
+struct ChainState { bool inproj_ready = false; int next_t = -1; };
 int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int T, int t, float w, uint64_t seed,
-             int first_sample, hipStream_t st) {
+             int first_sample, hipStream_t st, float** result = nullptr, ChainState* chain = nullptr) {
     int NB, n_cond, family;
     bool zero_spec;
     if (sampler_shape(sampler, B, NB, n_cond, family, zero_spec)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
     // Guidance weight 0: x0 = (1 + 0) c - 0 u = c (task/diffusion.py:953) - the unconditional evaluation is
     // multiplied by zero, so it is not run (half the work; the w = 0 points of the paper's guidance sweeps).
     if (w == 0.f && NB == 2 * B) { NB = B; n_cond = B; }
-    int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st, zero_spec);
-    if (rc) return rc;
     UpdateArgs u{};
     u.x = x; u.x0c = e->x0buf; u.x0u = (NB == 2 * B) ? e->x0buf + (size_t)B * T * 88 : nullptr;
     u.noise = noise; u.coef = e->d_coef + ((size_t)family * e->S + t) * 5; u.t = t; u.mode = family;
@@ -728,13 +790,28 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
     u.w = w; u.onepw = (float)(1.0 + (double)w);
     u.seed = seed; u.first_sample = first_sample;
     u.dyn = e->use_dyn ? e->d_dyn : nullptr;
+    TailPlan plan;
+    plan.u = u; plan.x_out = e->xalt; plan.u_B = B;
+    plan.next_t = chain ? chain->next_t : -1;
+    plan.skip_inproj = chain && chain->inproj_ready;
+    // (x and the tail kernel's output buffer must differ: a caller that hands us xalt itself gets the unfused tail)
+    TailPlan* offer = (result && x != e->xalt) ? &plan : nullptr;
+    if (chain) chain->inproj_ready = false;
+    int rc = run_network(e, x, B, NB, n_cond, T, t, e->x0buf, st, zero_spec, nullptr, offer);
+    if (rc) return rc;
+    if (offer && plan.done) {
+        *result = e->xalt;
+        if (chain) chain->inproj_ready = plan.inproj_done;
+        return DR_OK;
+    }
+    if (result) *result = x;
     HIPCHK(e, launch_update(u, st));
     return DR_OK;
 }
 
 // After a barrier time-out (device idle): re-arm the group counters, forget the published XCC tags, lower both flags.
 int clear_stack_timeout(dr_engine* e) {
-    HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(4 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));
+    HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(16 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));    // all four counter arrays
     HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));
     HIPCHK(e, hipMemset(e->stack_derr, 0, 16 * sizeof(unsigned)));
     *e->stack_err_host = 0;
@@ -815,6 +892,7 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
     e->NM = cfg->n_mels;
     if (const char* v = getenv("DR_STACK")) e->opt_stack = atoi(v);           // tuning / A-B experiments
     if (const char* v = getenv("DR_STACK_XCD")) e->opt_stack_xcd = atoi(v);
+    if (const char* v = getenv("DR_TAIL")) e->opt_tail = atoi(v);
     e->n_bins = cfg->n_fft / 2 + 1;
     e->bins_p = round_up(e->n_bins, 64);
     int maxdil = 1;
@@ -851,7 +929,7 @@ void dr_destroy(dr_engine* e) {
     for (auto& p : e->prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     float* bufs[] = {e->d_coef, e->d_dtab, e->h, e->hd, e->hd3, e->g3, e->g, e->skip, e->tmp, e->x0buf, e->cond, e->cond_dummy,
-                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->xwork, e->cond_tr};
+                     e->wav_pad, e->power, e->logmel, e->specP4, e->mm, e->sk_ws, e->xwork, e->cond_tr, e->xalt};
     for (float* p : bufs) if (p) (void)hipFree(p);
     delete e;
 }
@@ -1076,11 +1154,15 @@ int dr_commit(dr_engine* e, void* stream) {
     if (!e->d_dyn) { void* q = nullptr; HIPCHK(e, hipMalloc(&q, sizeof(DynParams))); e->d_dyn = (DynParams*)q; }
     if (!e->stack_bar) {     // group counters of the fused residual stack: zero between launches (re-armed in-kernel)
         void* q = nullptr;
-        const size_t nb = (size_t)(4 * dr_engine::STACK_GROUPS + 1024 + 16) * sizeof(unsigned);
+        const size_t G4 = (size_t)4 * dr_engine::STACK_GROUPS;
+        const size_t nb = (4 * G4 + 1024 + 16) * sizeof(unsigned);
         HIPCHK(e, hipMalloc(&q, nb));
         HIPCHK(e, hipMemset(q, 0, nb));
-        e->stack_bar = (unsigned*)q;
-        e->stack_xid = e->stack_bar + 4 * dr_engine::STACK_GROUPS;      // one word per block (<= 1024 CUs)
+        e->stack_bar = (unsigned*)q;                                     // [bar][pbar][tail bar][tail pbar][xid][derr]
+        e->stack_pbar = e->stack_bar + G4;
+        e->tail_bar = e->stack_bar + 2 * G4;
+        e->tail_pbar = e->stack_bar + 3 * G4;
+        e->stack_xid = e->stack_bar + 4 * G4;                            // one word per block (<= 1024 CUs)
         e->stack_derr = e->stack_xid + 1024;
         HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));   // no tag of a launch ever equals 0xFFFFFFFF
         // the "a barrier wait gave up" flag lives in host-visible memory: every later API call sees it without a
@@ -1271,7 +1353,11 @@ int dr_step(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, 
     int NB, n_cond;
     if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
     if ((rc = ensure_workspace(e, NB, T))) return rc;
-    return run_step(e, sampler, d_x, d_noise, B, T, t, w, seed, first_sample, (hipStream_t)stream);
+    float* res = nullptr;
+    if ((rc = run_step(e, sampler, d_x, d_noise, B, T, t, w, seed, first_sample, (hipStream_t)stream, &res))) return rc;
+    if (res != d_x)      // the fused step wrote x_{t-1} into the engine's buffer: hand it back in place
+        HIPCHK(e, hipMemcpyAsync(d_x, res, (size_t)B * T * 88 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DR_OK;
 }
 
 int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T, float w, uint64_t seed,
@@ -1286,12 +1372,28 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     hipStream_t st = (hipStream_t)stream;
     const size_t per = (size_t)B * T * 88;
     auto chain = [&](float* xbuf) -> int {
+        // the roll ping-pongs between xbuf and e->xalt while the fused step runs (its tail kernel cannot update in
+        // place), and each tail also computes the next step's input projection
+        ChainState cs;
+        float* cur = xbuf;
         for (int t = e->S - 1; t >= 0; --t) {
             // row t of the injected noise is the z of step t; t == 0 draws none (task/diffusion.py:957-960)
             const float* z = d_noise ? d_noise + (size_t)t * per : nullptr;
-            int r = run_step(e, sampler, xbuf, z, B, T, t, w, seed, first_sample, st);
+            cs.next_t = t - 1;
+            float* res = nullptr;
+            int r;
+            if (cur == e->xalt) {      // the previous step left the roll in the engine's buffer: this one writes back into xbuf
+                float* keep = e->xalt;
+                e->xalt = xbuf;
+                r = run_step(e, sampler, cur, z, B, T, t, w, seed, first_sample, st, &res, &cs);
+                e->xalt = keep;
+            } else {
+                r = run_step(e, sampler, cur, z, B, T, t, w, seed, first_sample, st, &res, &cs);
+            }
             if (r) return r;
+            cur = res;
         }
+        if (cur != xbuf) HIPCHK(e, hipMemcpyAsync(xbuf, cur, per * sizeof(float), hipMemcpyDeviceToDevice, st));
         return DR_OK;
     };
     if (!use_graph || e->prof) {
@@ -1398,6 +1500,12 @@ int dr_stack_fallbacks(dr_engine* e, int64_t* count) {
     return DR_OK;
 }
 
+int dr_tail_launches(dr_engine* e, int64_t* count) {
+    if (!e || !count) return DR_EINVAL;
+    *count = e->tail_launches;
+    return DR_OK;
+}
+
 int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end, void* stream) {
     if (!e || !d_roll || !d_note_end) return fail(e, DR_EINVAL, "null argument");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
@@ -1499,6 +1607,7 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
     };
     if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
     if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
+    if (n == "fused_tail") { if (e->opt_tail != value) drop_graph(); e->opt_tail = value; return DR_OK; }
     if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop_graph(); e->opt_stack_warm = value; return DR_OK; }
     if (n == "stack_fault_test") { if (e->opt_stack_fault != value) drop_graph(); e->opt_stack_fault = value; return DR_OK; }
     if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop_graph(); e->stack_dbg_on = value; return DR_OK; }

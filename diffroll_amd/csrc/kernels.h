@@ -176,6 +176,34 @@ struct UpdateArgs {
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
 
+// Tail of a reverse step as one persistent launch (tail_kernel in kernels.hip): skip projection -> output projection ->
+// classifier-free combine + posterior update -> input projection of the next step.  Same grid / grouping as the
+// stack_kernel launch it follows: NB samples (first `dual` conditional, next `dual` unconditional when dual > 0) x
+// ceil(T / BN) frame tiles x Cp / 64 blocks, all resident at once.
+struct TailArgs {
+    int NB, T, Cp, BN;                        // BN = frames per block of the preceding stack launch (64 / 128): grouping only
+    int dual;                                 // B > 0: classifier-free pairs (sample b, sample b + B); 0: every sample on its own
+    int u_B;                                  // rolls to update (B)
+    int xcd_n, fault;
+    float alpha;                              // 1 / sqrt(residual_layers)
+    const float* skip;                        // P4 [NB][Cp/4][T][4]
+    float* tmp;                               // P4 workspace, same shape
+    float* x0;                                // (NB, T, 88): network outputs (u.x0c / u.x0u point into it)
+    const float *skip_w, *skip_b, *outp_w, *outp_b, *zero;
+    UpdateArgs u;                             // the update of this step; u.x = x_t is only READ here
+    float* x_out;                             // x_{t-1} is written here (never u.x: other blocks still read x_t)
+    const float *in_w, *in_b, *d2_next;       // input projection of the NEXT step (in_w null: the chain ends here / single step)
+    float *h, *hd;                            // its outputs, P4 [NB][Cp/4][T][4]
+    // the next step's shared first-layer conv (dual > 0 and in_w set; conv_w null: none): layer 0 as in StackLayer
+    const float *conv_w, *conv_b, *conv_b2, *cond, *cond2;
+    long c_bs;
+    int taps, dil;
+    float* g;                                 // its output, P4 [NB][Cp/4][T][4]
+    int lds_bytes;                            // set by the launcher
+    unsigned *bar, *pbar, *err, *derr;        // counters as in StackArgs (own arrays), time-out flags (shared with the stack)
+};
+hipError_t launch_tail(const TailArgs& s, hipStream_t st);
+
 hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pad, hipStream_t s);
 // STFT power by FFT (N a power of two): wav_pad (B, Lp) -> power (B, TF, bins_p) row-major; win (N) the window,
 // tw (N complex) = exp(-2 pi i k / N), norm = sqrt(sum win^2) (the spectrum is divided by it)

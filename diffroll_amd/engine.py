@@ -217,6 +217,13 @@ class Engine:
         self._check(self.lib.dr_stack_fallbacks(self.h, C.byref(n)))
         return int(n.value)
 
+    @property
+    def tail_launches(self) -> int:
+        """Tail-kernel launches issued so far (option 'fused_tail')."""
+        n = C.c_int64(0)
+        self._check(self.lib.dr_tail_launches(self.h, C.byref(n)))
+        return int(n.value)
+
     def sample(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], w: float = 0.0,
                seed: int = 0, first_sample: int = 0, use_graph: bool = True, check: bool = True) -> torch.Tensor:
         """Whole reverse chain in place on x (B, T, 88); noise (S, B, T, 88) or None (Philox).

@@ -219,6 +219,8 @@ int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_nois
                       float w, uint64_t seed, int first_sample, int use_graph, int32_t* recovered, void* stream);
 /* how many time-outs dr_finish has detected (and healed) on this engine so far */
 int dr_stack_fallbacks(dr_engine* e, int64_t* count);
+/* tail-kernel launches issued so far (option "fused_tail"; a captured chain counts once, at capture) */
+int dr_tail_launches(dr_engine* e, int64_t* count);
 
 /*
  * Roll -> notes, the scan of extract_notes_wo_velocity (task/diffusion.py:1185-1233) as the reference's
@@ -295,6 +297,13 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          chip's CUs in one resident round (the BASELINE configurations 2-4 do); 0 = one launch per
  *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches); 2 = fuse
  *                          also launches that fill less than half the chip (tests).
+ *   "fused_tail"       [1] where the evaluation is one fused launch of the 64 / 128-frame flavours, the REST of a reverse
+ *                          step is fused too (model/diffwave.py:667-668, :682-686; task/diffusion.py:953-967): under
+ *                          classifier-free guidance the first layer's dilated conv - the same contraction for the
+ *                          conditional and the unconditional evaluation - becomes phase 0 of the fused launch (done
+ *                          once per pair of evaluations), and skip projection, output projection, combine + posterior
+ *                          update and the NEXT step's input projection run as one persistent "tail" launch: 2 launches
+ *                          per reverse step instead of 6.  0 = separate launches (bit-identical without split-K).
  *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
  *                          0 = one weight panel per XCD.  Performance only.
  *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that

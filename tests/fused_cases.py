@@ -80,6 +80,23 @@ def main():
             spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
             want = R.reverse_step(p, hp, sch, sampler, x, spec, 3, z, 0.5)
         rec["vs_oracle"] = float((ref.cpu() - want).abs().max())
+        # the whole 6-step chain (captured graph): with the fused step every tail kernel also computes the next
+        # step's input projection and the roll ping-pongs between two buffers - bit-identical to per-phase launches,
+        # with the tail fusion on and off
+        nz = torch.randn(hp["timesteps"], B, 1, Tn, 88, generator=g)
+        eng.set_option("fused_stack", 0)
+        chain_ref = m.sample(x, wav, noise=nz)[0]
+        for tailopt in (1, 0):
+            eng.set_option("fused_stack", 2)
+            eng.set_option("fused_stack_xcd", 1)
+            eng.set_option("fused_tail", tailopt)
+            t0 = eng.tail_launches
+            got = m.sample(x, wav, noise=nz)[0]
+            flag, _ = eng.stack_status()
+            rec["runs"].append({"xcd": 1, "chain": True, "tail": tailopt, "tail_launches": eng.tail_launches - t0,
+                                "timed_out": flag, "launches": 1, "kernel": rec["runs"][0]["kernel"],
+                                "equal": bool(torch.equal(got, chain_ref)), "maxdiff": float((got - chain_ref).abs().max())})
+        eng.set_option("fused_tail", 1)
         out.append(rec)
         del m
     if ni == 1:
