@@ -730,6 +730,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             }
         }
         ta.bar = e->tail_bar; ta.pbar = e->tail_pbar; ta.err = e->stack_err; ta.derr = e->stack_derr;
+        // ticks 112..119 of dr_stack_status: the last tail launch of a chain that has a next step (all its parts run)
+        ta.dbg = (e->stack_dbg_on && tail->next_t >= 0) ? e->stack_dbg + 112 : nullptr;
         HIPCHK(e, launch_tail(ta, st));
         e->tail_launches += 1;
         tail->done = true;

@@ -200,6 +200,8 @@ struct TailArgs {
     int taps, dil;
     float* g;                                 // its output, P4 [NB][Cp/4][T][4]
     int lds_bytes;                            // set by the launcher
+    long long* dbg;                           // optional: block 0 writes s_memtime at the start and after T1, its barrier, T2, its
+                                              // barrier, T3, its barrier, T4 (8 marks)
     unsigned *bar, *pbar, *err, *derr;        // counters as in StackArgs (own arrays), time-out flags (shared with the stack)
 };
 hipError_t launch_tail(const TailArgs& s, hipStream_t st);

@@ -2026,6 +2026,9 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
     unsigned* pctr = s.pbar + 4 * pair_i;
     const int P = s.Cp >> 2;
     const long act_bs = (long)s.Cp * s.T;
+    int mark_i = 0;
+    auto mark = [&]() { if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[mark_i] = clock64(); ++mark_i; };
+    mark();
 
     // ---- T1: skip projection (C x C) + relu, alpha = 1 / sqrt(L)
     {
@@ -2040,7 +2043,9 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
         if (wave < 4)
             for (int it = member; it < n1; it += (int)gsize) pw_body<2, 1, 0, 64, EPI_RELU>(a, it % a.MT, grp * tps64 + it / a.MT, wave);
     }
+    mark();
     group_barrier<true>(ctr, gsize + (unsigned)s.fault, s.err, s.derr);
+    mark();
     // ---- T2: output projection (88 x C) into the roll layout
     const int tps32 = (s.T + 31) >> 5;
     {
@@ -2053,8 +2058,10 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
         if (wave < 3)      // rows 96 .. 127 of the tile do not exist
             for (int it = member; it < tps32; it += (int)gsize) pw_body<1, 1, 0, 32, EPI_PLAIN>(a, 0, grp * tps32 + it, wave);
     }
+    mark();
     if (paired) group_barrier<true>(pctr, 2u * gsize + (unsigned)s.fault, s.err, s.derr);
     else group_barrier<true>(ctr, 2u * (gsize + (unsigned)s.fault), s.err, s.derr);
+    mark();
     // ---- T3: combine + update (+ the next step's input projection) per (row tile, 32-frame chunk) of the pair's clip
     if (pair_i < s.u_B) {       // (groups without a roll of their own - none today - would skip)
         const int MTi = s.in_w ? ((s.Cp + 127) >> 7) : 1;
@@ -2120,9 +2127,11 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
             }
         }
     }
+    mark();
     // ---- T4: the next step's shared first-layer conv (pairs only)
     if (paired && s.conv_w) {
         group_barrier<false>(pctr, 2u * (2u * gsize + (unsigned)s.fault), s.err, s.derr);
+        mark();
         GemmArgs a{};
         a.d2 = s.zero; a.wt_store = 0;                    // g is consumed by the NEXT launch: plain stores
         a.lds_bytes = s.lds_bytes;
@@ -2141,6 +2150,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
             gemm_body<1, 1, EPI_GATE, 0, 1>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
         }
     }
+    if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[7] = clock64();
     // leave: re-arm the counters (nobody polls them any more: everyone passed its last barrier before arriving here)
     if (threadIdx.x == 0) {
         const unsigned left = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

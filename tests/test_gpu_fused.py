@@ -104,8 +104,13 @@ def test_fused_stack_soak_under_uneven_load():
     z = torch.randn(B, 1, Tn, 88)
     eng = m.engine
     eng.set_option("fused_stack", 0)
-    ref = m.reverse_diffusion(x, wav, 2, noise=z)[0]
+    per_phase = m.reverse_diffusion(x, wav, 2, noise=z)[0]
     eng.set_option("fused_stack", 2)
+    # (in THIS process the per-phase launches may split K - the narrow output projection does - so they agree with
+    # the fused step to fp32 round-off; bitwise identity with pinned flavours is the test above.  The reference every
+    # repetition must reproduce bit for bit is the fused step's own first, quiet, result.)
+    ref = m.reverse_diffusion(x, wav, 2, noise=z)[0]
+    assert float((ref - per_phase).abs().max()) <= 2e-6
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, device="cuda")
     # mapping 1: every group inside one XCD (plain stores, shared L2); mapping 0: groups span all XCDs, so every
