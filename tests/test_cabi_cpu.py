@@ -128,3 +128,33 @@ def test_comm_entry_points_fail_cleanly_without_a_gpu():
         assert b"out of range" in lib.dr_comm_last_error() and not h.value
     assert lib.dr_comm_create(None, None, 1, 0, 0) == _cabi.DR_EINVAL
     assert lib.dr_gather(None, None, None, None, 1, 1, None) == _cabi.DR_EINVAL
+
+
+def test_round3_entry_points_reject_bad_calls_without_a_gpu(lib):
+    """dr_finish / dr_sample_checked / the counters and the checker hooks: NULL handles are an error code, never a
+    crash; the production library says that it is not a checker build."""
+    from diffroll_amd import _cabi
+    assert lib.dr_finish(None, None) == _cabi.DR_EINVAL
+    assert lib.dr_sample_checked(None, 1, None, None, 1, 1, 0.5, 0, 0, 1, None, None) == _cabi.DR_EINVAL
+    n = C.c_int64(7)
+    assert lib.dr_stack_fallbacks(None, C.byref(n)) == _cabi.DR_EINVAL and lib.dr_tail_launches(None, C.byref(n)) == _cabi.DR_EINVAL
+    assert lib.dr_debug_stft_power(None, None, 1, 4096, None, None) == _cabi.DR_EINVAL
+    out = (C.c_int64 * 4)()
+    if "bounds" not in os.path.basename(_cabi.LIB_PATH):
+        assert lib.dr_debug_bounds(out, 0) == _cabi.DR_ESTATE and b"checker build" in lib.dr_last_error(None)
+        assert _cabi.bounds_violations() is None
+    assert lib.dr_debug_bounds(None, 0) == _cabi.DR_EINVAL
+    assert _cabi.DR_ETIMEOUT == -6
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    assert re.search(r"DR_ETIMEOUT\s*=\s*-6", text)
+
+
+def test_checker_build_variants_are_declared():
+    """tools/checked_build.sh drives diffroll_amd.build's variants: the -DDR_BOUNDS kernels and the ASan/UBSan host."""
+    from diffroll_amd import build
+    assert set(build.VARIANTS) == {"bounds", "asan"}
+    assert "-DDR_BOUNDS" in build.VARIANTS["bounds"]["flags"]
+    assert any("-fsanitize=address" in f for f in build.VARIANTS["asan"]["flags"])
+    assert build.variant_path("bounds").endswith("libdiffroll_amd_bounds.so")
+    src = open(os.path.join(ROOT, "diffroll_amd", "csrc", "kernels.hip")).read()
+    assert src.count("DR_CHECK_LDS(") >= 12 and "check_gemm_extents" in src      # the instrumentation is there

@@ -524,3 +524,34 @@ def test_bench_workloads_match_the_survey_figures():
         assert fx == want and 0.95 * fl < fx < fl, (c, fx, fl)
     # the reference's own shipping geometry (sampling.py:27, config/sampling.yaml:11) is a bench workload
     assert bench.CONFIGS[6]["L"] // 512 == 640 and bench.CONFIGS[6]["B"] == 4 and bench.CONFIGS[7]["L"] // 512 == 640
+
+
+def test_output_frames_follow_trim_spec_roll():
+    """sample()'s roll length (what an EMPTY shard of a batch-sharded job must also report, diffroll_amd/distributed.py):
+    min(T, L // hop + 1) for the conditional samplers, T for generation - or 641, the learned unconditional
+    spectrogram's length, under condition='trainable_spec' (model/diffwave.py:30-39, :600-606, :656-662)."""
+    from diffroll_amd import ClassifierFreeDiffRoll
+    sa = dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000, center=True,
+              normalized=True, pad_mode="reflect")
+
+    def make(cond, sampler):
+        return ClassifierFreeDiffRoll(64, False, cond, 229, [0, 1, "imagewise"], residual_layers=2, kernel_size=3,
+                                      dilation_base=2, sampling={"type": sampler, "w": 0.5}, spec_args=sa)
+    m = make("fixed", "cfdg_ddpm_x0")
+    assert m.output_frames(640, 327680) == 640 and m.output_frames(700, 327680) == 641 and m.output_frames(125, 64000) == 125
+    g = make("fixed", "generation_ddpm_x0")
+    assert g.output_frames(640, None) == 640 and g.output_frames(700, 327680) == 641 and g.output_frames(900, None) == 900
+    t = make("trainable_spec", "generation_ddpm_x0")
+    assert t.output_frames(900, None) == 641 and t.output_frames(640, None) == 640
+    # the empty shard of more ranks than clips has exactly that many frames
+    from diffroll_amd.distributed import sample_shard
+
+    class Eng:
+        device = torch.device("cpu")
+    orig = type(t).__dict__["engine"]
+    type(t).engine = property(lambda self: Eng())           # (no GPU here: the shard helper only asks for the device)
+    try:
+        out = sample_shard(t, torch.zeros(1, 1, 900, 88), None, None, 0, rank=1, world_size=2)
+    finally:
+        type(t).engine = orig
+    assert tuple(out.shape) == (0, 1, 641, 88)

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence under profiles/ - run ON THE GPU BOX:
-#     gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02 gpurun_out/prof'
+#     gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r03 gpurun_out/prof'
 # then copy gpurun_out/prof/<round>_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter set per
 # pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
 set -u
-RD=${1:-r02}
+RD=${1:-r03}
 R=$PWD
 OUT=$R/${2:-gpurun_out/prof}
 mkdir -p "$OUT"
@@ -13,11 +13,11 @@ cd /tmp
 PS="python $R/tools/prof_summary.py"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_kt.log" 2>&1
 echo "kernel trace rc=$?"
-$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split (MI355X, config 2; stack_kernel<NI> = fused residual stack: 14 dilated convs + 15 1x1 per launch; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log; the gemm_kernel<..,3,..> rows here are layer 0's conv + the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
+$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split (MI355X, config 2: TWO launches per reverse step - stack_kernel<NI> = fused residual stack, 14 dilated convs + 15 1x1 per launch; tail_kernel = skip / output projection + combine + update + next input projection + next shared first-layer conv; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log - those rows are the front-end, each chain's first input projection / first-layer conv, and the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline > "$OUT/bench_kt1.log" 2>&1
 $PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
 rm -rf "$OUT/kt1"
-for cfg in 1 2 3 4 5; do
+for cfg in 1 2 3 4 5 6 7; do
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
 echo "fetch cfg$cfg rc=$?"
 timeout 400 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/pw$cfg" -o pw -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pw$cfg.log" 2>&1
@@ -34,21 +34,26 @@ echo "lds rc=$?"
 $PS "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_lds.txt"
 cd "$R"
 mkdir -p profiles_tmp && cp "$OUT"/${RD}_dominant_cfg*_traffic.json profiles/ 2>/dev/null   # so that bench.py finds the stamped record
-for c in 1 2 3 4 5; do
+for c in 1 2 3 4 5 6 7; do
   extra="--no-split --no-cpu-baseline"; [ $c = 2 ] && extra=""
   timeout 900 python bench.py --config $c $extra > "$OUT/${RD}_bench_cfg$c.json" 2> "$OUT/bench_cfg$c.err"; echo "bench cfg$c rc=$?"
 done
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
-rm -rf "$OUT/kt" "$OUT"/pf[1-5] "$OUT"/pw[1-5] "$OUT/pm" "$OUT/pl" profiles_tmp
+rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
+timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
+timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"
+timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
+timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" > "$OUT/${RD}_scale_table.txt" 2>&1
 head -14 "$OUT/${RD}_kernel_stats.txt"
 cat "$OUT"/${RD}_dominant_cfg*_traffic.json
 grep -A8 "stack_kernel" "$OUT/${RD}_stack_pmc_mfma.txt" | head -12
-for c in 1 2 3 4 5; do python - "$OUT/${RD}_bench_cfg$c.json" <<'PY'
+for c in 1 2 3 4 5 6 7; do python - "$OUT/${RD}_bench_cfg$c.json" <<'PY'
 import json,sys
 try:
     j=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r=j.get("roofline",{})
-    print(sys.argv[1].split("/")[-1], j["value"], j["ms_per_step"], "roofline", r.get("frac"), "traffic", r.get("traffic"), r.get("traffic_source"), j.get("whole_chain",{}).get("frac_of_fp32_mfma_peak"), j.get("hbm_roofline",{}).get("frac"))
+    w=j.get("whole_chain",{})
+    print(sys.argv[1].split("/")[-1], j["value"], j["ms_per_step"], "roofline", r.get("frac"), "traffic", r.get("traffic"), r.get("traffic_source"), "executed", w.get("executed_frac_of_fp32_mfma_peak"), "algorithmic", w.get("algorithmic_frac_of_fp32_mfma_peak"), j.get("hbm_roofline",{}).get("frac"))
 except Exception as e:
     print("ERR", sys.argv[1], e)
 PY
