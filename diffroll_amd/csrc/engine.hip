@@ -383,6 +383,8 @@ Tile pick_pointwise_tile(int MT, int NB, int T, int prec) {
     if (!pw) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
     if (pw_ni) return Tile{2, pw_ni};
     // launches that cannot fill half the chip even with 64-frame blocks: the LDS-staged kernel with split-K
+    // (measured and rejected in round 3: 32-frame blocks of the direct kernel instead - 64 blocks at config 1 -
+    // 35.2 vs 34.0 ms per chain)
     if ((long)MT * NB * ((T + 63) / 64) <= 128) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
     // cost = block rounds over the 256 CUs x frames per block; 64-frame blocks carry a measured 7 % penalty
     // (twice the operand loads per MFMA)

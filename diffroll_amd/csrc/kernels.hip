@@ -1088,15 +1088,35 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
     pw_body<NW, 0, 0>(a, mt, nt, wave);
 }
 
+// Block -> XCD mapping of a per-phase GEMM launch (see gemm_kernel): 0 = one weight panel (M tile) per XCD, 1 = the M
+// tiles of a frame tile share an XCD.  Chosen by the bytes each choice pulls through the XCDs' L2s (what the FETCH
+// counters see): with mapping 0 every XCD streams ITS panel once (L2-resident if it fits) and all of X; with mapping 1
+// every XCD streams its share of X once and ALL panels - once if the whole weight matrix fits its L2, else once per
+// round of concurrently resident frame tiles.  (Until round 3 the rule was "xbytes > wbytes", which picked mapping 1
+// for 5-round launches of big convs - 640-frame generation batches - and paid 13.9x the algorithmic traffic.)
+static int pick_xcd_mapping(int MT, int NT, double wbytes, double xbytes) {
+    if (MT <= 1 || NT % 8 != 0) return 0;
+    static const int force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;      // tuning experiments
+    if (force >= 0) return force;
+    static const int model = getenv("DR_XCD_MODEL") ? atoi(getenv("DR_XCD_MODEL")) : 1;
+    if (!model) return xbytes > wbytes ? 1 : 0;
+    const double l2 = 4.0 * 1024 * 1024, cus_per_xcd = 32.0;
+    const double conc = cus_per_xcd / MT < 1.0 ? 1.0 : cus_per_xcd / MT;               // frame tiles resident per XCD (mapping 1)
+    const double rounds1 = wbytes <= l2 ? 1.0 : ((NT / 8.0) / conc < 1.0 ? 1.0 : (NT / 8.0) / conc);
+    const double cost1 = 8.0 * rounds1 * wbytes + xbytes;
+    const double panel = wbytes / MT;
+    const double rounds0 = panel <= l2 ? 1.0 : (double)((long)MT * NT + 255) / 256;    // a panel that does not fit is re-streamed per round
+    const double cost0 = rounds0 * wbytes + 8.0 * xbytes;
+    return cost1 < cost0 ? 1 : 0;
+}
+
 template <int NW>
 static hipError_t launch_pw_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 32 * NW;
     const int NT = a.NB * ((a.T + BN - 1) / BN);
     GemmArgs b = a;
-    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks, xbytes = (double)NT * BN * 32.0 * a.kchunks;
-    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
-    static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
-    if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
+    const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks, xbytes = 4.0 * (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = pick_xcd_mapping(a.MT, NT, wbytes, xbytes);
     DR_CHECK_EXTENTS(b, EPI_RES_SKIP, 0, "pw_kernel");
     hipLaunchKernelGGL((pw_kernel<NW>), dim3((unsigned)(a.MT * NT)), dim3(256), 0, s, b);
     return hipGetLastError();
@@ -1719,8 +1739,8 @@ static hipError_t launch_gemm16_t(const GemmArgs& a, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * ((a.T + BN - 1) / BN);
     GemmArgs b = a;
-    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
-    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
+    const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = 4.0 * (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = pick_xcd_mapping(a.MT, NT, wbytes, xbytes);
     b.lds_bytes = (int)lds;
     DR_CHECK_EXTENTS(b, EPI, 0, "gemm16_kernel");
     hipLaunchKernelGGL((gemm16_kernel<NJ, KS, EPI>), dim3((unsigned)(a.MT * NT)), dim3(512), lds, s, b);
@@ -1779,10 +1799,8 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     b.lds_bytes = (int)lds;
     const dim3 grid((unsigned)(a.MT * NT * b.ksplit));
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
-    const double wbytes = 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = (double)NT * BN * 32.0 * a.kchunks;
-    b.xcd_n = (a.MT > 1 && NT % 8 == 0 && xbytes > wbytes) ? 1 : 0;
-    static const int xcd_force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;    // tuning experiments
-    if (xcd_force >= 0 && a.MT > 1 && NT % 8 == 0) b.xcd_n = xcd_force;
+    const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = 4.0 * (double)NT * BN * 32.0 * a.kchunks;
+    b.xcd_n = pick_xcd_mapping(a.MT, NT, wbytes, xbytes);
     DR_CHECK_EXTENTS(b, EPI, PREC, "gemm_kernel");
     hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
