@@ -42,6 +42,11 @@ VARIANTS = {
     "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
     "asan": dict(flags=["-O1", "-g", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"],
                  link=["-fsanitize=address,undefined", "-shared-libsan"]),
+    #   ubsan:  the host side under UndefinedBehaviorSanitizer alone (-fno-sanitize-recover: the first finding aborts).
+    #           This is the variant that can run ON THE GPU BOX: the HIP runtime does not initialise under ASan's
+    #           allocator (segfault inside hipInit), UBSan does not touch the allocator
+    "ubsan": dict(flags=["-O1", "-g", "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-fno-omit-frame-pointer"],
+                  link=["-fsanitize=undefined", "-shared-libsan", "@RPATH:libclang_rt.ubsan_standalone-x86_64.so"]),
 }
 
 
@@ -70,7 +75,14 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
             relink = True
         objs.append(o)
     if relink or _stale(lib, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + extra["link"] + objs + ["-ldl", "-o", lib]
+        link = []
+        for f in extra["link"]:
+            if f.startswith("@RPATH:"):      # the directory of a compiler runtime library, as an rpath of the output
+                rt = subprocess.check_output([hipcc, "-print-file-name=" + f[len("@RPATH:"):]], text=True).strip()
+                link.append("-Wl,-rpath," + os.path.dirname(os.path.realpath(rt)))
+            else:
+                link.append(f)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + link + objs + ["-ldl", "-o", lib]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -131,9 +131,26 @@ def main():
             n0 = eng.stack_launches
             got = m.reverse_diffusion(x, wav, 3, noise=z)[0]
             flag, _ = eng.stack_status()
-            out.append({"case": [label], "vs_oracle": 0.0,
-                        "runs": [{"xcd": 1, "timed_out": flag, "launches": eng.stack_launches - n0, "kernel": "stack_kernel<1>",
-                                  "equal": bool(torch.equal(got, ref)), "maxdiff": float((got - ref).abs().max())}]})
+            rec = {"case": [label], "vs_oracle": 0.0,
+                   "runs": [{"xcd": 1, "timed_out": flag, "launches": eng.stack_launches - n0, "kernel": "stack_kernel<1>",
+                             "equal": bool(torch.equal(got, ref)), "maxdiff": float((got - ref).abs().max())}]}
+            # ... and as a whole chain: the tail kernel's next-step first-layer conv (T4) with the learned unconditional
+            # conditioner / the spec == 0 bias, against per-phase launches (bitwise) and the oracle's loop
+            nz = torch.randn(hp["timesteps"], B, 1, Tn, 88, generator=g)
+            eng.set_option("fused_stack", 0)
+            chain_ref = m.sample(x, wav, noise=nz)[0]
+            eng.set_option("fused_stack", 2)
+            t0 = eng.tail_launches
+            chain = m.sample(x, wav, noise=nz)[0]
+            flag, _ = eng.stack_status()
+            hpc = dict(hp, condition=cond)
+            with torch.no_grad():
+                want = R.sample_chain(sd, hpc, sampler, x, wav, nz, w=0.5)
+            rec["vs_oracle"] = float((chain.cpu() - want).abs().max())
+            rec["runs"].append({"xcd": 1, "chain": True, "tail_launches": eng.tail_launches - t0, "timed_out": flag, "launches": 1,
+                                "kernel": "stack_kernel<1>", "equal": bool(torch.equal(chain, chain_ref)),
+                                "maxdiff": float((chain - chain_ref).abs().max())})
+            out.append(rec)
     from diffroll_amd import _cabi
     v = _cabi.bounds_violations()          # checker builds (tools/checked_build.sh): this process's own record
     if v is not None:

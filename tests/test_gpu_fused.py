@@ -53,6 +53,10 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
             assert run["timed_out"] == 0 and run["launches"] >= 1, rec
             assert run["kernel"] == f"stack_kernel<{ni}>", rec
             assert run["equal"], rec
+            if run.get("chain"):      # whole chains: the tail kernel ran (or, switched off / 160-frame flavour, did not)
+                # (an evaluation that needs several fused launches - sample chunks - keeps the separate tail launches)
+                want_tail = ni != 5 and run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1
+                assert (run["tail_launches"] >= 1) == want_tail, rec
 
 
 def test_fused_stack_with_per_sample_steps_and_whole_chain():
