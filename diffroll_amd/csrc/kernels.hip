@@ -344,9 +344,14 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         issue(c0);
 #endif
         for (int chunk = c0; chunk < c1; ++chunk) {
-            // hand-over #chunk: __syncthreads() waits for this wave's DMA (vmcnt) before the barrier; the
-            // consumers' matching barrier opens their chunk.  Only then may the OTHER buffer be refilled
-            // (the consumers finished reading it before they arrived here).
+            // hand-over #chunk: this wave's DMA of tile #chunk must have LANDED before the barrier releases the
+            // consumers - barriers do not drain VMEM, and hipcc does not reliably insert the wait for a
+            // __syncthreads() behind LDS-DMA builtins (it did in the stand-alone kernels and did NOT in the fused
+            // ones: tools/isa_audit.py; the consumers then read the previous occupant of the buffer whenever the tile
+            // was slower than their own first weight fragments - observed with cross-XCD hand-offs).  Hence explicit.
+            // The consumers' matching barrier opens their chunk; only then may the OTHER buffer be refilled (the
+            // consumers finished reading it before they arrived here).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
 #if DR_ABLATE != 9
             if (chunk + 1 < c1) issue(chunk + 1);
@@ -1527,6 +1532,7 @@ DR_DEVINL void gemm16_body(const GemmArgs& a, char* smem, const int mt, const in
         }
         issue(0);
         for (int chunk = 0; chunk < nchunks; ++chunk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile #chunk has landed (see gemm_body)
             __syncthreads();
             if (chunk + 1 < nchunks) issue(chunk + 1);
         }
@@ -2164,6 +2170,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
         const int tps64 = (s.T + 63) >> 6;
         const int n4 = MT * tps64;
         for (int it = pair_half * (int)gsize + member; it < n4; it += 2 * (int)gsize) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                              // (the LDS tiles of the previous item / of T3 are free)
             gemm_body<1, 1, EPI_GATE, 0, 1>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
         }

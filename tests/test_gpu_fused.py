@@ -136,3 +136,24 @@ def test_fused_stack_soak_under_uneven_load():
 
 # (what happens when a group barrier can NOT complete - bounded spins, the flag, dr_finish, the re-run on the per-phase
 # kernels - is covered by tests/test_gpu_r3.py)
+
+
+@pytest.mark.parametrize("flavour,args", [("5", ["--T", "640", "--reps", "40"]), ("", ["--T", "500", "--reps", "24"]),
+                                          ("", ["--T", "250", "--reps", "24"])])
+def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
+    """tools/xcd_stress.py: the full-depth (15-layer) full-width net with 32-block groups, block mapping 0 (every group
+    spread over all eight XCDs: every hand-off crosses XCDs, and the X tiles of a conv phase arrive from memory instead
+    of the local L2) against mapping 1, bit for bit, repeatedly - the 160-frame flavour (DR_STACK_FL=5: this is the
+    geometry that exposed the missing wait before the LDS-DMA hand-over barrier, 25 % of the runs) and the 128- / 64-frame
+    ones."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if flavour:
+        env["DR_STACK_FL"] = flavour
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "xcd_stress.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    assert "RESULT ok" in r.stdout, r.stdout[-2000:]
+    want = f"stack_kernel<{flavour or ('2' if '500' in args else '1')}>"
+    assert want in r.stdout, r.stdout[-500:]
