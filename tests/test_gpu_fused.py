@@ -139,7 +139,8 @@ def test_fused_stack_soak_under_uneven_load():
 
 
 @pytest.mark.parametrize("flavour,args", [("5", ["--T", "640", "--reps", "40"]), ("", ["--T", "500", "--reps", "24"]),
-                                          ("", ["--T", "250", "--reps", "24"])])
+                                          ("", ["--T", "250", "--reps", "24"]),
+                                          ("", ["--T", "500", "--chain", "6", "--reps", "16"])])     # chains: the tail kernel too
 def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
     """tools/xcd_stress.py: the full-depth (15-layer) full-width net with 32-block groups, block mapping 0 (every group
     spread over all eight XCDs: every hand-off crosses XCDs, and the X tiles of a conv phase arrive from memory instead

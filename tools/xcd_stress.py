@@ -22,10 +22,12 @@ def main():
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--sampler", default="cfdg_ddpm_x0")
     ap.add_argument("--layers", type=int, default=15)
+    ap.add_argument("--chain", type=int, default=0, help="> 0: whole captured chains of that many steps (tail kernel incl. the "
+                                                         "next step's input projection / first-layer conv) instead of single steps")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     hp = dict(bench.HP)
-    hp.update(kernel_size=args.k, timesteps=200, residual_layers=args.layers)
+    hp.update(kernel_size=args.k, timesteps=args.chain if args.chain > 0 else 200, residual_layers=args.layers)
     m = bench.build_model(dev, hp=hp, sampler=args.sampler)
     eng = m.engine
     g = torch.Generator().manual_seed(11)
@@ -34,16 +36,25 @@ def main():
     z = torch.randn(args.B, 1, args.T, 88, generator=g).to(dev)
     eng.set_option("fused_stack", 2)
     eng.set_option("fused_stack_xcd", 1)
+    if args.chain > 0:
+        chain_noise = torch.randn(args.chain, args.B, 1, args.T, 88, generator=g).to(dev)
+
+        def run():
+            return m.sample(x, wav, noise=chain_noise)[0]
+    else:
+        def run():
+            return m.reverse_diffusion(x, wav, 150, noise=z)[0]
     eng.profile_enable(True)
-    ref = m.reverse_diffusion(x, wav, 150, noise=z)[0]
+    ref = m.reverse_diffusion(x, wav, min(150, hp["timesteps"] - 1), noise=z)[0]
     _, _, _, kname = eng.profile_read_ex()
     eng.profile_enable(False)
-    again = m.reverse_diffusion(x, wav, 150, noise=z)[0]
+    ref = run()
+    again = run()
     print(f"kernel {kname.split(' ')[0]}; mapping 1 repeatable: {bool(torch.equal(ref, again))}")
     eng.set_option("fused_stack_xcd", 0)
     bad = 0
     for r in range(args.reps):
-        out = m.reverse_diffusion(x, wav, 150, noise=z)[0]
+        out = run()
         flag, _ = eng.stack_status()
         eq = bool(torch.equal(out, ref))
         d = float((out - ref).abs().max())
