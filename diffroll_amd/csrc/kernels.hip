@@ -1237,6 +1237,9 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         member = blockIdx.x % (int)gsize;
         grp = blockIdx.x / (int)gsize;
     }
+    // (a launch whose evaluations are not a multiple of 8 is padded with idle groups - launch_stack - so that the
+    // group-per-XCD dealing stays whole: their blocks have nothing to do and touch no counter)
+    if (grp >= s.NB) return;
     mt = member % MT;                                     // sample (clip evaluation) grp = barrier group
     nt = grp * tps + member / MT;
     // A time-out of an earlier launch of this engine that the host has not cleared yet (dr_finish / dr_stack_status):
@@ -1416,6 +1419,25 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     }
 }
 
+// Group-per-XCD dealing of a persistent launch (block b is dispatched to XCD b % 8): groups g, g + 8, g + 16, ... share
+// XCD g, so it needs every XCD's share - ceil(NB / 8) groups - to fit that XCD's CUs.  When NB is not a multiple of 8
+// the grid is padded with idle groups (their blocks exit at once) if that still holds; else the launch falls back to
+// the spread mapping (groups across all XCDs, write-through hand-offs).
+static int xcd_padded_groups(int NB, int gsize, int* xcd_n) {
+    if (!*xcd_n) return NB;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const int per_xcd = (NB + 7) / 8;
+    if (NB % 8 == 0) return NB;
+    if (per_xcd * gsize * 8 <= cus) return per_xcd * 8;
+    *xcd_n = 0;
+    return NB;
+}
+
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st) {
     if (FL != 1 && FL != 2 && FL != 5) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
@@ -1425,8 +1447,7 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     StackArgs b = s;
     b.rs_off = (int)(lds - 16 - (size_t)32 * BN * 16);
     b.lds_bytes = (int)lds;
-    const int NT = s.NB * tps;
-    if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;            // the group-per-XCD mapping deals groups round-robin to 8 XCDs
+    const int NBp = xcd_padded_groups(s.NB, MT * tps, &b.xcd_n);
 #ifdef DR_BOUNDS
     for (int l = 0; l < s.L; ++l) {
         GemmArgs g{};
@@ -1441,7 +1462,7 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     host_extent(s.bar, (size_t)4 * 512 * 4, "group counters", "stack_kernel");
     host_extent(s.xid, (size_t)1024 * 4, "tag words", "stack_kernel");
 #endif
-    const dim3 grid((unsigned)(MT * NT));
+    const dim3 grid((unsigned)(MT * tps * NBp));
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
     else hipLaunchKernelGGL((stack_kernel<5>), grid, dim3(512), lds, st, b);
@@ -2041,6 +2062,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
         member = blockIdx.x % (int)gsize;
         grp = blockIdx.x / (int)gsize;
     }
+    if (grp >= s.NB) return;                                                               // padding group (launch_tail)
     if (__hip_atomic_load(s.derr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;     // see stack_kernel
     DR_CHECK(grp >= 0 && grp < 512, 150, grp, member);
     unsigned* ctr = s.bar + 4 * grp;
@@ -2200,7 +2222,7 @@ hipError_t launch_tail(const TailArgs& s, hipStream_t st) {
     if (!s.x_out || s.x_out == s.u.x) return hipErrorInvalidValue;
     const int tps = (s.T + s.BN - 1) / s.BN, MT = s.Cp >> 6;
     TailArgs b = s;
-    if (b.xcd_n && s.NB % 8 != 0) b.xcd_n = 0;
+    const int NBp = xcd_padded_groups(s.NB, MT * tps, &b.xcd_n);       // idle padding groups, as launch_stack
     size_t lds = 24 * 32 * 16;
     if (s.conv_w) {
         if (s.dual <= 0 || (s.taps & 1) == 0) return hipErrorInvalidValue;
@@ -2208,7 +2230,7 @@ hipError_t launch_tail(const TailArgs& s, hipStream_t st) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;
     }
     b.lds_bytes = (int)lds;
-    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(MT * tps * s.NB)), dim3(512), lds, st, b);
+    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)(MT * tps * NBp)), dim3(512), lds, st, b);
     return hipGetLastError();
 }
 

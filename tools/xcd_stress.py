@@ -65,6 +65,16 @@ def main():
             where = f" mismatches {len(nz)}: samples {sorted(set(nz[:, 0].tolist()))}, frames {int(fr.min())}..{int(fr.max())}"
         print(f"mapping 0 rep {r}: timed_out={flag} equal={eq} max|diff|={d:.3e}{where}", flush=True)
         bad += (not eq)
+    import time
+    for mapping in (1, 0):
+        eng.set_option("fused_stack_xcd", mapping)
+        run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        print(f"mapping {mapping}: {1e3 * (time.perf_counter() - t0) / 5:.3f} ms per {'chain' if args.chain else 'step'}")
     print("RESULT", "FAIL" if bad else "ok", bad, "of", args.reps)
 
 
