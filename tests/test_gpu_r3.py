@@ -196,7 +196,10 @@ def test_config2_real_batch_200_step_chain_vs_oracle():
     noise = torch.randn(200, B, 1, Tn, 88, generator=g)
     roll, _ = m.sample(x, wav, noise=noise)
     m.engine.stack_status()
-    assert m.engine.stack_launches >= 1 and m.engine.fallbacks == 0     # the fused kernel is what ran
+    import os
+    if os.environ.get("DR_STACK", "1") != "0":                          # (DR_STACK=0: a forced-mode run of the suite)
+        assert m.engine.stack_launches >= 1                             # the fused kernel is what ran
+    assert m.engine.fallbacks == 0
     with torch.no_grad():
         ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
     roll = roll.cpu()

@@ -211,7 +211,8 @@ def test_two_processes_share_the_gpu_and_gather(tmp_path):
         assert p.returncode == 0 and "RANK_DONE" in so, (so[-1500:], se[-3000:])
         done = [ln for ln in so.splitlines() if ln.startswith("RANK_DONE")][-1].split()
         assert done[2] == "0", so                       # no barrier time-out in either process
-        assert int(done[3]) > 0, so                     # and the fused kernel is what ran (192 blocks per process)
+        if os.environ.get("DR_STACK", "1") != "0":      # (DR_STACK=0: a forced-mode run of the suite)
+            assert int(done[3]) > 0, so                 # and the fused kernel is what ran (192 blocks per process)
     got = torch.load(res)
     hp, p, m = _model(layers=3, steps=8, C=512)
     torch.manual_seed(5)
