@@ -40,6 +40,7 @@ VARIANTS = {
     #   asan:   the HOST side (engine.hip, comm.hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
     #           UndefinedBehaviorSanitizer; device code is compiled as usual (-fno-gpu-sanitize)
     "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
+    "ablate1": dict(flags=["-DDR_ABLATE=1"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments
     "asan": dict(flags=["-O1", "-g", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"],
                  link=["-fsanitize=address,undefined", "-shared-libsan"]),
     #   ubsan:  the host side under UndefinedBehaviorSanitizer alone (-fno-sanitize-recover: the first finding aborts).

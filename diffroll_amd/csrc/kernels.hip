@@ -1310,7 +1310,10 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     for (int p = s.p0; p < s.p1; ++p) {
         const int l = p >> 1;
         const __attribute__((address_space(4))) StackLayer& ly = sp->layer[l];
-        if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[p - s.p0] = clock64();
+        if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+            s.dbg[p - s.p0] = clock64();
+            if (p == s.p0) s.dbg[120] = wall_clock64();          // constant 100 MHz: gives the shader clock the launch ran at
+        }
         GemmArgs a{};
         a.d2 = s.zero;
         a.lds_bytes = s.lds_bytes;
@@ -1357,13 +1360,21 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // tiles have nothing to do
             const bool idle = last && mt < (s.Cp >> 7);
             if (s.dbg && p + 3 == s.p1) a.dbg = s.dbg + 96;       // second-to-last 1x1 phase (block 0 works in it)
-            if (wave < 4 && !idle) {
-                if constexpr (FL == 5) {
-                    pw_body<3, 1, 1, 160>(a, mt, nt, wave, Rs, 0);
-                    pw_body<2, 1, 1, 160>(a, mt, nt, wave, Rs, 96);
-                } else {
-                    pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
+            // 128- / 160-frame flavours: all eight waves contract the 1x1 - the producers have nothing to stage in this
+            // phase, so waves w and w + 4 share the rows of wave w and split its frames (two MFMA streams per SIMD
+            // cover each other's fragment waits and epilogue; 64 fewer live registers in the merged kernel: 204
+            // instead of 256 + 16 B of scratch).  Same k order per output: bit-identical.  Measured at config 2:
+            // 1x1 phase 76.9 k -> 73.7 k cycles, chain 883.1 -> 879.3 ms.  The 64-frame flavour keeps four waves:
+            // with one 32-frame tile per wave the phase takes the same cycles at a lower clock (485.4 vs 483.3 ms).
+            if constexpr (FL == 5) {
+                if (!idle) {
+                    if (wave < 4) pw_body<3, 1, 1, 160>(a, mt, nt, wave, Rs, 0);
+                    else pw_body<2, 1, 1, 160>(a, mt, nt, wave - 4, Rs, 96);
                 }
+            } else if constexpr (FL == 2) {
+                if (!idle) pw_body<2, 1, 1, 128>(a, mt, nt, wave & 3, Rs, (wave >> 2) * 64);
+            } else {
+                if (wave < 4 && !idle) pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
             }
             if (wave >= 4 && s.warm && !last) {
                 // idle for the whole 1x1 phase: fetch the first two chunks (2 x taps slabs of 16 KB) of the next
@@ -1389,7 +1400,10 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             }
         }
     }
-    if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[s.p1 - s.p0] = clock64();
+    if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+        s.dbg[s.p1 - s.p0] = clock64();
+        s.dbg[121] = wall_clock64();
+    }
     // write the resident tile back: skip always (the skip projection reads it next), h only when layers remain
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -208,6 +208,31 @@ def test_config2_real_batch_200_step_chain_vs_oracle():
     assert _thresholded_equal(roll, ref, ATOL_STEP)
 
 
+@pytest.mark.parametrize("sampler, inp_t, seed", [("generation_ddpm_x0", None, 3016), ("inpainting_ddpm_x0", [31, 62], 4016)],
+                         ids=["config3_generation", "config4_inpainting"])
+def test_config3_config4_real_batch_200_step_chains_vs_oracle(sampler, inp_t, seed):
+    """BASELINE configs 3 and 4 at their per-GPU batch (16 clips, 125 frames, k = 9), all 200 steps with identical
+    injected noise: unconditional generation (spec = -1: 16 evaluations per step on the 64-frame fused flavour) and
+    inpainting (spectrogram span masked, guided: 32 evaluations, fused stack + tail kernel) against the oracle's loop
+    (task/diffusion.py:528-534 with the samplers of :971-997 / :999-1028)."""
+    hp = dict(R.DEFAULT_HP)
+    p = R.synthetic_params(hp, seed=seed % 97)
+    m = make_model(hp, p, sampler=sampler, w=0.5, inpainting_t=inp_t)
+    g = torch.Generator().manual_seed(seed)
+    B, Tn = 16, 125
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    noise = torch.randn(200, B, 1, Tn, 88, generator=g)
+    roll, _ = m.sample(x, wav, noise=noise)
+    assert m.engine.fallbacks == 0
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, sampler, x, wav, noise, w=0.5, inpainting_t=inp_t)
+    roll = roll.cpu()
+    d = maxdiff(roll, ref)
+    assert d <= ATOL_STEP, d
+    assert _thresholded_equal(roll, ref, ATOL_STEP)
+
+
 def test_config5_200_step_chain_single_clip_vs_oracle():
     """BASELINE config 5's network and clip length - k = 15, 640 frames - as a whole 200-step guided chain of one clip
     (per-phase launches: 16x16-MFMA conv tiles, 160-frame 1x1 blocks, split-K where the launch under-fills)."""

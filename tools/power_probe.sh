@@ -1,19 +1,25 @@
 #!/bin/bash
-# Sample socket power and shader clock (rocm-smi) while a chain runs:  bash tools/power_probe.sh [f32|bf16x3]
+# Sample socket power and shader clock (rocm-smi) while a chain runs:  bash tools/power_probe.sh [f32|bf16x3] [config]
 PREC=${1:-f32}
-python - "$PREC" <<'PY' &
+CFG=${2:-2}
+python - "$PREC" "$CFG" <<'PY' &
 import sys, time, torch
 sys.path.insert(0, '.')
 import bench
 dev = torch.device('cuda', 0)
-m = bench.build_model(dev); m.precision = sys.argv[1]
+cfg = bench.CONFIGS[int(sys.argv[2])]
+hp = dict(bench.HP); hp.update(kernel_size=cfg["k"], timesteps=cfg["S"])
+m = bench.build_model(dev, hp=hp, sampler=cfg["sampler"]); m.precision = sys.argv[1]
 g = torch.Generator().manual_seed(0)
-wav = (0.1 * torch.randn(16, 64000, generator=g)).to(dev); x = torch.randn(16, 1, 125, 88, generator=g).to(dev)
+B, T = cfg["B"], cfg["L"] // 512
+wav = (0.1 * torch.randn(B, cfg["L"], generator=g)).to(dev); x = torch.randn(B, 1, T, 88, generator=g).to(dev)
 m.sample(x, wav, seed=0); torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(12): m.sample(x, wav, seed=0)
+N = max(4, int(10e3 / max(cfg['B'] * T / 4.0, 1)))
+N = 12 if int(sys.argv[2]) in (2, 4) else (24 if int(sys.argv[2]) == 3 else 8)
+for _ in range(N): m.sample(x, wav, seed=0)
 torch.cuda.synchronize()
-print("chain ms", (time.perf_counter() - t0) / 12 * 1e3, flush=True)
+print("chain ms", (time.perf_counter() - t0) / N * 1e3, flush=True)
 PY
 PID=$!
 sleep 6

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--level", type=int, default=1, help="fused_stack option value (2 = forced, e.g. with DR_STACK_FL=5)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = bench.CONFIGS[args.config]
@@ -40,7 +41,7 @@ def main():
     ref = step()
     torch.cuda.synchronize()
     for xcd in (1, 0):
-        eng.set_option("fused_stack", 1)
+        eng.set_option("fused_stack", args.level)
         eng.set_option("fused_stack_xcd", xcd)
         for rep in range(3):
             out = step()
@@ -63,7 +64,7 @@ def main():
     print(f"unfused: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, "
           f"first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
     eng.set_option("stack_ticks", 0)
-    eng.set_option("fused_stack", 1)
+    eng.set_option("fused_stack", args.level)
     # phase ticks (shader-clock cycles of block 0, barrier waits included)
     for xcd in (1, 0):
         eng.set_option("fused_stack_xcd", xcd)
@@ -71,8 +72,11 @@ def main():
         step()
         flag, ticks = eng.stack_status(128)
         print(f"xcd={xcd}: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
+        wall = ticks[121] - ticks[120]                 # constant 100 MHz counter over the same span as the phase marks
         ticks = ticks[:2 * hp["residual_layers"] + 2]
         nz = [t for t in ticks[:-1] if t]
+        if wall > 0 and len(nz) > 1:
+            print(f"xcd={xcd}: block 0 ran {nz[-1] - nz[0]} shader cycles in {wall / 100:.1f} us = {(nz[-1] - nz[0]) / wall * 100:.1f} MHz")
         if len(nz) > 1:
             d = [b - a for a, b in zip(nz[:-1], nz[1:])]
             tail, d = d[-1], d[:-1]                 # the last mark pair brackets the write-back of the resident tile
@@ -98,7 +102,7 @@ def main():
     eng.set_option("fused_stack", 0)
     t_un, r_un = chain_ms()
     for xcd, warm in ((1, 1), (1, 0), (0, 1)):
-        eng.set_option("fused_stack", 1)
+        eng.set_option("fused_stack", args.level)
         eng.set_option("fused_stack_xcd", xcd)
         eng.set_option("fused_stack_warm", warm)
         t_f, r_f = chain_ms()
