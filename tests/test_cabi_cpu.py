@@ -152,7 +152,7 @@ def test_round3_entry_points_reject_bad_calls_without_a_gpu(lib):
 def test_checker_build_variants_are_declared():
     """tools/checked_build.sh drives diffroll_amd.build's variants: the -DDR_BOUNDS kernels and the ASan/UBSan host."""
     from diffroll_amd import build
-    assert set(build.VARIANTS) == {"bounds", "asan", "ubsan"}
+    assert {"bounds", "asan", "ubsan"} <= set(build.VARIANTS)          # (+ measurement builds)
     assert "-DDR_BOUNDS" in build.VARIANTS["bounds"]["flags"]
     assert any("-fsanitize=address" in f for f in build.VARIANTS["asan"]["flags"])
     assert build.variant_path("bounds").endswith("libdiffroll_amd_bounds.so")
