@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--level", type=int, default=1, help="fused_stack option value (2 = forced, e.g. with DR_STACK_FL=5)")
+    ap.add_argument("--batch", type=int, default=0, help="override the configuration's batch (clips per GPU)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = bench.CONFIGS[args.config]
@@ -28,7 +29,7 @@ def main():
     m = bench.build_model(dev, hp=hp, sampler=cfg["sampler"])
     eng = m.engine
     g = torch.Generator().manual_seed(5)
-    B = cfg["B"]
+    B = args.batch or cfg["B"]
     wav = (0.1 * torch.randn(B, cfg["L"], generator=g)).to(dev)
     x = torch.randn(B, 1, T, 88, generator=g).to(dev)
     z = torch.randn(B, 1, T, 88, generator=g).to(dev)
