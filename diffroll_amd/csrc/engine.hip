@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -459,8 +460,11 @@ int build_trainable_cond(dr_engine* e, int T) {
     return DR_OK;
 }
 
+void drop_graph(dr_engine* e);
+
 int ensure_workspace(dr_engine* e, int NB, int T) {
     if (NB <= e->ws_NB && T == e->ws_T) return DR_OK;
+    drop_graph(e);       // a captured chain holds the addresses of the buffers that are about to be replaced
     const int nb = std::max(NB, e->ws_T == T ? e->ws_NB : 0);
     const size_t act = (size_t)nb * e->Cp * T;
     int rc;
@@ -1451,9 +1455,8 @@ int dr_finish(dr_engine* e, void* stream) {
     drop_graph(e);
     e->opt_stack = 0;
     e->stack_fallbacks += 1;
-    static bool warned = false;
-    if (!warned) {
-        warned = true;
+    static std::atomic<bool> warned{false};           // (engines of several host threads may get here together)
+    if (!warned.exchange(true)) {
         fprintf(stderr, "[diffroll_amd] a group barrier of the fused residual-stack kernel timed out (another stream, engine or "
                         "process is computing on device %d): this engine now uses one launch per phase (option fused_stack = 0); "
                         "results since the last check are recomputed\n", e->cfg.device);

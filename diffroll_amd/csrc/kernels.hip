@@ -1439,12 +1439,12 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
 // the spread mapping (groups across all XCDs, write-through hand-offs).
 static int xcd_padded_groups(int NB, int gsize, int* xcd_n) {
     if (!*xcd_n) return NB;
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    static const int cus = [] {                         // (thread-safe one-time initialisation)
+        int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
     const int per_xcd = (NB + 7) / 8;
     if (NB % 8 == 0) return NB;
     if (per_xcd * gsize * 8 <= cus) return per_xcd * 8;
