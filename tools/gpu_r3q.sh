@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 3, final: refresh the profiles for the current sources, then the repeatability soaks on the same build
+set -u
+O=gpurun_out/soak; mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+bash tools/refresh_profiles.sh r03 gpurun_out/prof > $O/refresh.log 2>&1; tail -8 $O/refresh.log
+S=$O/r03_soak.txt; : > $S
+{
+echo "# repeatability soaks on the round-3 build (one MI355X); every line is a tool's own summary"
+echo "## tools/fused_soak.py --chains 30 --config 2   (30 x 200 fused launches + 30 x 200 tail launches, same seed: bitwise equal rolls, no time-out)"
+timeout 600 python tools/fused_soak.py --chains 30 --config 2 2>&1 | tail -3
+echo "## tools/fused_soak.py --chains 30 --config 3"
+timeout 600 python tools/fused_soak.py --chains 30 --config 3 2>&1 | tail -3
+echo "## tools/determinism_soak.py 600   (split-K path: small launches, every chain twice)"
+timeout 900 python tools/determinism_soak.py 600 2>&1 | tail -3
+echo "## tools/xcd_stress.py: block mapping 0 (groups spread over the XCDs) must reproduce mapping 1 bit for bit"
+for fl in 0 5; do for T in 500 640; do
+  echo "# DR_STACK_FL=$fl --T $T --reps 40"
+  if [ $fl = 5 ]; then export DR_STACK_FL=5; else unset DR_STACK_FL; fi
+  timeout 600 python tools/xcd_stress.py --T $T --B 4 --reps 40 2>&1 | tail -2
+done; done
+unset DR_STACK_FL
+echo "# --T 250 --B 8 --reps 40 (64-frame flavour)"; timeout 600 python tools/xcd_stress.py --T 250 --B 8 --reps 40 2>&1 | tail -2
+echo "# --T 500 --chain 20 --reps 10 (whole chains, tail kernel)"; timeout 900 python tools/xcd_stress.py --T 500 --B 4 --chain 20 --reps 10 2>&1 | tail -2
+echo "# --T 125 --B 9 --reps 40 (padded launch, 9 guided clips)"; timeout 600 python tools/xcd_stress.py --T 125 --B 9 --reps 40 2>&1 | tail -2
+} >> $S 2>&1
+cat $S
