@@ -373,20 +373,29 @@ int pick_ni(int MT, int NB, int T, int taps, int dil, int prec = 0) {
     return pick_tile(MT, NB, T, taps, dil, prec, EPI_GATE, false).n;
 }
 hipError_t launch_tiled(const GemmArgs& a, int epi, Tile t, hipStream_t s, int prec) {
+    if (t.flavor == 3) return launch_pointwise_ksplit(a, t.n, s);
     if (t.flavor == 2) return launch_pointwise(a, t.n, s);
     return t.flavor == 1 ? launch_gemm16(a, epi, t.n, s) : launch_gemm(a, epi, t.n, s, prec);
 }
 // tile of the 1x1 residual/skip GEMM: flavor 2 = operands direct from L2 (pw_kernel), fp32 only
-Tile pick_pointwise_tile(int MT, int NB, int T, int prec) {
+Tile pick_pointwise_tile(int MT, int NB, int T, int prec, int kchunks = 0) {      // kchunks: 32-channel slabs of K (default: MT tiles cover all rows)
     if (prec) return Tile{0, 1};
     static const int pw = getenv("DR_PW") ? atoi(getenv("DR_PW")) : 1;          // tuning experiments: 0 = LDS-staged kernels
     static const int pw_ni = getenv("DR_PW_NW") ? atoi(getenv("DR_PW_NW")) : 0;    // force 32*NW-frame blocks
     if (!pw) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
     if (pw_ni) return Tile{2, pw_ni};
-    // launches that cannot fill half the chip even with 64-frame blocks: the LDS-staged kernel with split-K
-    // (measured and rejected in round 3: 32-frame blocks of the direct kernel instead - 64 blocks at config 1 -
-    // 35.2 vs 34.0 ms per chain)
-    if ((long)MT * NB * ((T + 63) / 64) <= 128) return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
+    // launches that cannot fill half the chip even with 64-frame blocks (single clips): 32-row x 32-frame tiles whose
+    // four waves split K in-block (flavor 3, pwk_kernel: 256 blocks at config 1, 13.9 -> 8 us per launch); without it
+    // (DR_PWK=0, K splitting pinned off, a channel count that is not a multiple of 128) the LDS-staged kernel with
+    // split-K through the workspace.  (Measured and rejected in round 3: 32-frame blocks of the direct kernel instead -
+    // 64 blocks at config 1 - 35.2 vs 34.0 ms per chain.)
+    if ((long)MT * NB * ((T + 63) / 64) <= 128) {
+        static const int pwk = getenv("DR_PWK") ? atoi(getenv("DR_PWK")) : 1;
+        static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;
+        if (pwk && ks_max > 1 && (kchunks ? kchunks : 2 * MT) % 4 == 0)
+            return Tile{3, (long)4 * MT * NB * ((T + 31) / 32) <= 512 ? 1 : 2};
+        return pick_tile(MT, NB, T, 1, 1, 0, EPI_RES_SKIP, true);
+    }
     // cost = block rounds over the 256 CUs x frames per block; 64-frame blocks carry a measured 7 % penalty
     // (twice the operand loads per MFMA)
     struct Cand { int nw; double pen; };
@@ -700,12 +709,12 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             Tile tile = pick_pointwise_tile(Cp / 64, NB, T, prec);
             // the last layer's residual output is never read (model/diffwave.py:678-682 only uses the skip sum
             // after the loop): launch the skip half of the M tiles only
-            if (l + 1 == L && tile.flavor == 2) {
+            if (l + 1 == L && tile.flavor >= 2) {
                 // packed rows [0, Cp) are the residual half: the first 128-row tile holding a skip row is Cp / 128
                 // (when Cp is not a multiple of 128 that tile also recomputes a few residual rows: harmless)
                 const int first = Cp / 128, count = Cp / 64 - first;
-                const Tile half = pick_pointwise_tile(count, NB, T, prec);
-                if (half.flavor == 2) { tile = half; a.MT = count; a.mt0 = first; }
+                const Tile half = pick_pointwise_tile(count, NB, T, prec, Cp / 32);
+                if (half.flavor == tile.flavor) { tile = half; a.MT = count; a.mt0 = first; }
             }
             HIPCHK(e, launch_tiled(a, EPI_RES_SKIP, tile, st, prec));
         }

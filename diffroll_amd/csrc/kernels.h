@@ -102,6 +102,7 @@ hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 // 1x1 EPI_RES_SKIP GEMM with both operands direct from L2 (no LDS): block = 128 rows x 32*NW frames
 // (NW in {2,3,4,5}), 256 threads
 hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
+hipError_t launch_pointwise_ksplit(const GemmArgs& a, int NW, hipStream_t s);   // under-filled launches: 32-row tiles, K split over the block's waves
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 
 // ---------------------------------------------------------------------------------------------

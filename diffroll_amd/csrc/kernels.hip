@@ -1093,6 +1093,161 @@ __global__ __launch_bounds__(256) void pw_kernel(const GemmArgs a) {
     pw_body<NW, 0, 0>(a, mt, nt, wave);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 1x1 residual / skip GEMM for launches that cannot fill the chip (single clips: 2 evaluations x 125 frames are 32
+// of pw_kernel's tiles).  Block = 4 waves on ONE 32-row x 32*NW-frame output tile, the waves splitting K in-block: wave
+// w contracts the w-th quarter of the channel slabs (k ascending inside it) with both operands straight from L2, the
+// four partial tiles meet in LDS and are added in wave order ((p0 + p1) + p2) + p3 - deterministic, independent of
+// timing - and wave w runs the epilogue of register quad w (8 rows x 4... = one float4 of the P4 layout per lane and
+// frame tile).  256 blocks at config 1 with a K loop of 64 MFMAs per wave instead of 32 tiles x 8 K slices exchanged
+// through a workspace with tickets: 13.9 -> ~8 us per launch.  Same epilogue arithmetic as pw_body (EPI_RES_SKIP).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void pwk_kernel(const GemmArgs a) {
+    __shared__ float4 part[4][NW][4][64];                      // [wave][frame tile][quad][lane]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, hi = lane >> 5;
+    constexpr int BN = 32 * NW;
+    const int RT = a.MT * 4;                                   // 32-row tiles
+    const int rt = blockIdx.x % RT + a.mt0 * 4, nt = blockIdx.x / RT;
+    const int mt = rt >> 2, sr = rt & 3;                       // 128-row weight panel, 32-row sub-tile
+    const int tps = (a.T + BN - 1) / BN;
+    const int b = nt / tps;
+    const int t0 = (nt % tps) * BN;
+    const int NS = a.kchunks, NSW = NS >> 2;                   // slabs (32 channels) in all / per wave
+    const int s0 = wave * NSW;
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Wp + (long)mt * NS * 4096), 0, (unsigned)NS * 16384u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.X + (long)b * a.x_bs), 0, (unsigned)(a.x_planes * a.x_ps * 4), 0x00020000);
+    const int wvo = (hi * 128 + sr * 32 + r) * 16;
+    const int xps = (int)a.x_ps * 4;
+    int xvo[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) xvo[ni] = hi * xps + min(t0 + ni * 32 + r, a.T - 1) * 16;
+    auto asf4 = [](const u32x4 u) { return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)); };
+    struct AF { float4 v[4]; };
+    struct BF { float4 v[4][NW]; };
+    auto load_a = [&](int slab) -> AF {
+        AF o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 140, slab, NS);
+            o.v[g] = asf4(__builtin_amdgcn_raw_buffer_load_b128(wr, wvo, slab * 16384 + g * 4096, 0));
+        }
+        return o;
+    };
+    auto load_b = [&](int slab) -> BF {
+        BF o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni)
+                o.v[g][ni] = asf4(__builtin_amdgcn_raw_buffer_load_b128(xr, xvo[ni], (slab * 8 + g * 2) * xps, 0));
+        return o;
+    };
+    // the epilogue operands of THIS wave's quad (q = wave): requested first, their latency hides behind the K loop
+    const int p0 = mt * 128 + sr * 32 + 8 * wave + 4 * hi;     // first of the lane's 4 packed rows
+    const bool res_rows = p0 < a.y_rows;                       // wave-uniform (y_rows is a multiple of 64)
+    const float4 ebias = *reinterpret_cast<const float4*>(a.bias + p0);
+    const float4 ed2 = *reinterpret_cast<const float4*>(a.d2 + (a.tsel ? (long)a.tsel[b] * a.d2_ts : 0) + min(p0, a.y_rows - 4));
+    float4 eop[NW];
+    {
+        const float* base = res_rows ? a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps
+                                     : a.skip + (long)b * a.s_bs + (long)((p0 - a.y_rows) >> 2) * a.T * 4;
+        const long fs = res_rows ? a.y_fs : 4;
+#pragma unroll
+        for (int ni = 0; ni < NW; ++ni) eop[ni] = *reinterpret_cast<const float4*>(base + (long)min(t0 + ni * 32 + r, a.T - 1) * fs);
+    }
+
+    f32x16 acc[NW];
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ni][e] = 0.f;
+    AF aA = load_a(s0), aB;
+    BF bA = load_b(s0), bB;
+    auto mma = [&](const AF& af, const BF& bf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.v[g].x, bf.v[g][ni].x, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.v[g].y, bf.v[g][ni].y, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.v[g].z, bf.v[g][ni].z, acc[ni], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) acc[ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.v[g].w, bf.v[g][ni].w, acc[ni], 0, 0, 0);
+        }
+    };
+    int slab = 0;
+    for (; slab + 2 <= NSW; slab += 2) {          // two register sets, prefetch distance one slab
+        aB = load_a(s0 + slab + 1); bB = load_b(s0 + slab + 1);
+        mma(aA, bA);
+        const int nx = s0 + min(slab + 2, NSW - 1);
+        aA = load_a(nx); bA = load_b(nx);
+        mma(aB, bB);
+    }
+    if (slab < NSW) mma(aA, bA);
+
+    // the four partial tiles meet in LDS; wave w sums register quad w of every frame tile in wave order
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            part[wave][ni][q][lane] = make_float4(acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]);
+    __syncthreads();
+    auto f4arr = [](const float4 v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; };
+    float bb[4], dd[4];
+    f4arr(ebias, bb); f4arr(ed2, dd);
+#pragma unroll
+    for (int ni = 0; ni < NW; ++ni) {
+        const int t = t0 + ni * 32 + r;
+        if (t >= a.T) continue;
+        float v[4], pv[4], o[4], u[4];
+        f4arr(part[0][ni][wave][lane], v);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            f4arr(part[w][ni][wave][lane], u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += u[e];
+        }
+        f4arr(eop[ni], pv);
+        if (res_rows) {          // h = (h + (acc + b)) / sqrt(2) in place, hd = h + d_{l+1}   (model/diffwave.py:151, :139)
+            float* dst = a.Y + (long)b * a.y_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = div_sqrt2(pv[e] + (v[e] + bb[e]));
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            if (a.Y2) {
+                float* dst2 = a.Y2 + (long)b * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
+                *reinterpret_cast<float4*>(dst2) = make_float4(o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]);
+            }
+        } else {                 // skip (+)= acc + b   (model/diffwave.py:680)
+            float* dst = a.skip + (long)b * a.s_bs + ((long)((p0 - a.y_rows) >> 2) * a.T + t) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = a.skip_init ? v[e] + bb[e] : (v[e] + bb[e]) + pv[e];
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+template <int NW>
+static hipError_t launch_pwk_t(const GemmArgs& a, hipStream_t s) {
+    const int BN = 32 * NW;
+    const int NT = a.NB * ((a.T + BN - 1) / BN);
+    DR_CHECK_EXTENTS(a, EPI_RES_SKIP, 0, "pwk_kernel");
+    hipLaunchKernelGGL((pwk_kernel<NW>), dim3((unsigned)(a.MT * 4 * NT)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+// 1x1 EPI_RES_SKIP GEMM of an under-filled launch, fp32: block = 32 rows x 32*NW frames, K split over its 4 waves
+hipError_t launch_pointwise_ksplit(const GemmArgs& a, int NW, hipStream_t s) {
+    if (a.taps != 1 || a.kchunks < 4 || (a.kchunks & 3) || a.x_fs != 4 || a.out_s3) return hipErrorInvalidValue;
+    return NW == 1 ? launch_pwk_t<1>(a, s) : NW == 2 ? launch_pwk_t<2>(a, s) : hipErrorInvalidValue;
+}
+
 // Block -> XCD mapping of a per-phase GEMM launch (see gemm_kernel): 0 = one weight panel (M tile) per XCD, 1 = the M
 // tiles of a frame tile share an XCD.  Chosen by the bytes each choice pulls through the XCDs' L2s (what the FETCH
 // counters see): with mapping 0 every XCD streams ITS panel once (L2-resident if it fits) and all of X; with mapping 1
