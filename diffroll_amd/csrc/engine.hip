@@ -566,9 +566,10 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
             const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : (fl == 5 ? 1.04 : 1.0));
-            // (a single launch that fills less than half the chip is better served by the per-phase kernels'
-            // split-K, which this cost model does not see; opt_stack == 2 fuses regardless: tests)
-            const bool ok = e->opt_stack == 2 || (chunks == 1 ? 2 * NB * gsize >= e->n_cus : true);
+            // (a single launch that fills no more than half the chip is better served by the per-phase kernels'
+            // split-K, which this cost model does not see - at exactly half, 8 evaluations x 125 frames, 1365 vs 2422 us
+            // per step; opt_stack == 2 fuses regardless: tests)
+            const bool ok = e->opt_stack == 2 || (chunks == 1 ? 2 * NB * gsize > e->n_cus : true);
             if (ok && cost < best) { best = cost; stack_ni = fl; stack_chunks = (int)chunks; }
         }
         if (stack_ni && e->opt_stack != 2 && best > per_phase_cost()) stack_ni = 0;
