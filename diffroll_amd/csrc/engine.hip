@@ -79,7 +79,7 @@ struct dr_engine {
     // split-K workspace (partials) and ticket counters, see gemm_kernel
     float* sk_ws = nullptr;
     unsigned* sk_cnt = nullptr;
-    static constexpr size_t SK_WS_FLOATS = (size_t)8 << 20, SK_CNT_N = 4096;
+    static constexpr size_t SK_WS_FLOATS = (size_t)16 << 20, SK_CNT_N = 4096;     // 64 MiB: up to 1024 partial tiles of 128 x 128
     float *h = nullptr, *hd = nullptr, *g = nullptr, *skip = nullptr, *tmp = nullptr, *x0buf = nullptr;
     float* xwork = nullptr;                // the captured chain runs in place on this engine-owned roll buffer
     float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
@@ -566,10 +566,11 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
             const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : (fl == 5 ? 1.04 : 1.0));
-            // (a single launch that fills no more than half the chip is better served by the per-phase kernels'
-            // split-K, which this cost model does not see - at exactly half, 8 evaluations x 125 frames, 1365 vs 2422 us
-            // per step; opt_stack == 2 fuses regardless: tests)
-            const bool ok = e->opt_stack == 2 || (chunks == 1 ? 2 * NB * gsize > e->n_cus : true);
+            // (a single launch that leaves more than a fifth of the CUs idle is better served by the per-phase kernels'
+            // split-K, which this cost model does not see: they cut the same work into many short blocks that balance
+            // over all CUs - 8 evaluations x 125 frames (half the chip): 1365 vs 2422 us per step, 10 / 12 evaluations
+            // (62 / 75 %): 1994 / 2022 vs 2425, 14 (87 %): 2526 vs 2424; opt_stack == 2 fuses regardless: tests)
+            const bool ok = e->opt_stack == 2 || (chunks == 1 ? 5 * NB * gsize > 4 * (long)e->n_cus : true);
             if (ok && cost < best) { best = cost; stack_ni = fl; stack_chunks = (int)chunks; }
         }
         if (stack_ni && e->opt_stack != 2 && best > per_phase_cost()) stack_ni = 0;

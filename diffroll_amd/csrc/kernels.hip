@@ -1981,16 +1981,32 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * tps;
     GemmArgs b = a;
-    // Split-K for launches that cannot fill the chip: double the split while all blocks still fit in one
-    // round of the 256 CUs, every split keeps >= 1 chunk and the partials fit the workspace.
+    // Split-K: launches that cannot fill the chip, and (round 3) launches that fill it unevenly.  The ticket reduction
+    // needs no co-residency (nobody spins), so a launch may be cut into MORE blocks than the chip holds: 10 evaluations
+    // of 125 frames are 160 tiles = one round of full-K blocks on 62 % of the CUs; cut 4x in K they are 640 blocks =
+    // 3 rounds of quarter-length blocks: 136 -> 107 us per conv launch, 2410 -> 1996 us per reverse step.  Cost model in
+    // us per launch (fp32), fitted to 3..8 guided clips of 125 frames (tools/small_batch_ab.py: equal blocks run in
+    // lockstep rounds - 160 / 192 / 224 tiles cut 4x took 107 / 109 / 143 us): rounds x t_full / ks + exchange, with
+    // t_full = a full-K tile (MFMA count x 69 cycles) and the exchange (store, ticket, the last arriver's re-read of
+    // ks partials) ~(4 + ks) us.
     b.ksplit = 1;
     if (a.ws && a.ws_cnt) {
         static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
+        static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : (PREC ? 256 : 2048);
         const int nchunks = a.kchunks / KS;
         const long tiles = (long)a.MT * NT;
-        while (b.ksplit * 2 <= ks_max && tiles * b.ksplit * 2 <= 256 && nchunks % (b.ksplit * 2) == 0 &&
-               (size_t)tiles * (b.ksplit * 2) * 128 * BN <= a.ws_floats && (size_t)tiles * 4 <= a.ws_cnt_n)
-            b.ksplit *= 2;
+        const double t_full = (double)a.kchunks * a.taps * 16.0 * (2 * NI) * 69.0 / 2400.0;
+        auto cost = [&](int ks) {
+            return (double)((tiles * ks + 255) / 256) * t_full / ks + (ks > 1 ? 4.0 + ks : 0.0);
+        };
+        double best = cost(1);
+        for (int ks = 2; ks <= ks_max && ks <= 16; ks *= 2) {
+            if (tiles * ks > max_blocks || nchunks % ks != 0) break;
+            if ((size_t)tiles * ks * 128 * BN > a.ws_floats || (size_t)tiles * 4 > a.ws_cnt_n) break;
+            const double c = cost(ks);
+            // (inside one resident round more slices are taken as before; beyond it a split must win by 3 %)
+            if (tiles * ks <= 256 || c < 0.97 * best) { best = std::min(best, c); b.ksplit = ks; }
+        }
     }
     b.lds_bytes = (int)lds;
     const dim3 grid((unsigned)(a.MT * NT * b.ksplit));
