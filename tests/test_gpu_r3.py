@@ -284,6 +284,44 @@ def test_reference_shipping_geometry_640_frames_step_vs_oracle(sampler, B):
     eng.set_option("fused_stack", 1)
 
 
+@pytest.mark.parametrize("sampler,B,Tn", [("cfdg_ddpm_x0", 5, 125), ("cfdg_ddpm_x0", 3, 125), ("generation_ddpm_x0", 12, 125),
+                                          ("cfdg_ddpm_x0", 1, 640), ("cfdg_ddpm_x0", 10, 125)])
+def test_part_filled_launches_vs_oracle(sampler, B, Tn):
+    """Batches that fill 37-75 % of the chip with full-K blocks (3 / 5 / 10 guided clips, 12 generated ones, one 640-frame
+    clip): the launcher cuts their convs into more K slices than fit one resident round (ticket reduction, no
+    co-residency needed) and the fused kernel stands aside - one reverse step of the full network against the oracle,
+    twice (bitwise repeatable: the reduction order is fixed), and against the same step with K splitting capped to
+    one round through the fused kernel (forced)."""
+    hp = dict(R.DEFAULT_HP)
+    p = R.synthetic_params(hp, seed=3)
+    m = make_model(hp, p, sampler=sampler, w=0.5)
+    g = torch.Generator().manual_seed(7000 + 10 * B + Tn)
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    z = torch.randn(B, 1, Tn, 88, generator=g)
+    sch = R.schedule(hp["beta_start"], hp["beta_end"], hp["timesteps"])
+    with torch.no_grad():
+        spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
+        ref = R.reverse_step(p, hp, sch, sampler, x, spec, 61, z, 0.5)
+    w_arg = wav if sampler != "generation_ddpm_x0" else None
+    eng = m.engine
+    eng.stack_status()
+    n0 = eng.stack_launches
+    out = m.reverse_diffusion(x, w_arg, 61, noise=z)[0].cpu()
+    eng.stack_status()
+    import os
+    if os.environ.get("DR_STACK", "1") == "1":
+        assert eng.stack_launches == n0                      # the per-phase kernels ran (the launch fills < 80 % of the CUs)
+    assert maxdiff(out, ref) <= ATOL_STEP, (sampler, B, Tn)
+    again = m.reverse_diffusion(x, w_arg, 61, noise=z)[0].cpu()
+    assert torch.equal(out, again)
+    eng.set_option("fused_stack", 2)
+    fused = m.reverse_diffusion(x, w_arg, 61, noise=z)[0].cpu()
+    eng.set_option("fused_stack", 1)
+    assert maxdiff(fused, ref) <= ATOL_STEP
+    assert maxdiff(fused, out) <= 2e-6
+
+
 # --------------------------------------------------------------------------------------------
 # trained-weight regime: saturated gates, large pre-activations, large dynamic range
 # --------------------------------------------------------------------------------------------
