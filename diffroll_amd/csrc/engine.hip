@@ -364,7 +364,23 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
     for (const Cand& c : cands) {
         if (!feasible(c)) continue;
         const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
-        const double cost = (double)((blocks + 255) / 256) * c.bn * c.pen;
+        double cost = (double)((blocks + 255) / 256) * c.bn * c.pen;
+        // The 32x32 conv kernels may be cut in K into more blocks than CUs (launch_gemm's split-K cost model: equal
+        // blocks run in lockstep rounds, the exchange costs ~(4 + ks) us): a width whose tile count fills the chip
+        // unevenly can still win that way - 2 guided 640-frame clips: 320 64-frame tiles cut 4x, 3209 vs 3592 us per
+        // step on 224 96-frame tiles of the 16x16 kernel, which has no split.  Such a cost must win by 5 %.
+        if (c.flavor == 0 && prec == 0 && epi == EPI_GATE && taps > 1 && allow16) {
+            static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;
+            static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 2048;
+            const int nchunks = 2 * MT;                                                  // 32-channel chunks of K
+            const double us_per_frame = nchunks * taps * 16.0 * (c.bn / 32) * 69.0 / 2400.0 / c.bn;
+            for (int ks = 2; ks <= ks_max && ks <= 16 && blocks * ks <= max_blocks && nchunks % ks == 0 &&
+                             (size_t)blocks * ks * 128 * c.bn <= dr_engine::SK_WS_FLOATS; ks *= 2) {
+                if (blocks * ks <= 256) continue;                                        // (one resident round: the launcher's own business)
+                const double cs = 1.05 * ((double)((blocks * ks + 255) / 256) / ks * c.bn * c.pen + (4.0 + ks) / us_per_frame);
+                cost = std::min(cost, cs);
+            }
+        }
         if (cost < best_cost - 1e-9) { best_cost = cost; best = Tile{c.flavor, c.n}; }
     }
     return best;
