@@ -341,6 +341,24 @@ size_t expected_numel(const dr_engine* e, const std::string& name) {
 // CU) x (frames per block); 16x16 tiles carry a small penalty (more operand reads per MFMA), 128-frame
 // 32x32 tiles win ties.
 struct Tile { int flavor, n; };
+// The 32x32 conv kernels may be cut in K into more blocks than CUs (launch_gemm's split-K cost model: equal blocks run
+// in lockstep rounds, the exchange costs ~(4 + ks) us): a width whose tile count fills the chip unevenly can still win
+// that way - 2 guided 640-frame clips: 320 64-frame tiles cut 4x, 3209 vs 3592 us per step on 224 96-frame tiles of
+// the 16x16 kernel, which has no split.  Cost in the units of pick_tile (block rounds x frames per block x penalty) of
+// the best split that needs MORE than one resident round, with a 5 % handicap; 1e30 if there is none.
+double split_cost(long blocks, int bn, double pen, int MT, int taps) {
+    static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;
+    static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 2048;
+    const int nchunks = 2 * MT;                                                  // 32-channel chunks of K
+    const double us_per_frame = nchunks * taps * 16.0 * (bn / 32) * 69.0 / 2400.0 / bn;
+    double best = 1e30;
+    for (int ks = 2; ks <= ks_max && ks <= 16 && blocks * ks <= max_blocks && nchunks % ks == 0 &&
+                     (size_t)blocks * ks * 128 * bn <= dr_engine::SK_WS_FLOATS; ks *= 2) {
+        if (blocks * ks <= 256) continue;                                        // (one resident round: the launcher's own business)
+        best = std::min(best, 1.05 * ((double)((blocks * ks + 255) / 256) / ks * bn * pen + (4.0 + ks) / us_per_frame));
+    }
+    return best;
+}
 Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool allow16) {
     static const char* forced = getenv("DR_TILE");     // tuning experiments: "32:2", "16:5", ... (if it fits)
     const int halo = ((taps - 1) / 2) * dil;
@@ -365,22 +383,8 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
         if (!feasible(c)) continue;
         const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
         double cost = (double)((blocks + 255) / 256) * c.bn * c.pen;
-        // The 32x32 conv kernels may be cut in K into more blocks than CUs (launch_gemm's split-K cost model: equal
-        // blocks run in lockstep rounds, the exchange costs ~(4 + ks) us): a width whose tile count fills the chip
-        // unevenly can still win that way - 2 guided 640-frame clips: 320 64-frame tiles cut 4x, 3209 vs 3592 us per
-        // step on 224 96-frame tiles of the 16x16 kernel, which has no split.  Such a cost must win by 5 %.
-        if (c.flavor == 0 && prec == 0 && epi == EPI_GATE && taps > 1 && allow16) {
-            static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;
-            static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 2048;
-            const int nchunks = 2 * MT;                                                  // 32-channel chunks of K
-            const double us_per_frame = nchunks * taps * 16.0 * (c.bn / 32) * 69.0 / 2400.0 / c.bn;
-            for (int ks = 2; ks <= ks_max && ks <= 16 && blocks * ks <= max_blocks && nchunks % ks == 0 &&
-                             (size_t)blocks * ks * 128 * c.bn <= dr_engine::SK_WS_FLOATS; ks *= 2) {
-                if (blocks * ks <= 256) continue;                                        // (one resident round: the launcher's own business)
-                const double cs = 1.05 * ((double)((blocks * ks + 255) / 256) / ks * c.bn * c.pen + (4.0 + ks) / us_per_frame);
-                cost = std::min(cost, cs);
-            }
-        }
+        if (c.flavor == 0 && prec == 0 && epi == EPI_GATE && taps > 1 && allow16)
+            cost = std::min(cost, split_cost(blocks, c.bn, c.pen, MT, taps));
         if (cost < best_cost - 1e-9) { best_cost = cost; best = Tile{c.flavor, c.n}; }
     }
     return best;
@@ -567,6 +571,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             for (const auto& c : cands) {
                 const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
                 best = std::min(best, (double)((blocks + e->n_cus - 1) / e->n_cus) * c.bn * c.pen);
+                // (the 32x32 widths may split K beyond one round: 20 guided clips, 640 64-frame tiles cut 2x, 6166 us
+                // per step against 7074 as three fused launches of 13-14 evaluations)
+                if (c.bn == 64 || c.bn == 128) best = std::min(best, split_cost(blocks, c.bn, c.pen, MT, e->K));
             }
             return best;
         };
