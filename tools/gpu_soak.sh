@@ -1,9 +1,8 @@
 #!/bin/bash
-# round 3, final: refresh the profiles for the current sources, then the repeatability soaks on the same build
+# round 3, final: the repeatability soaks on the final build (profiles/r03_soak.txt)
 set -u
 O=gpurun_out/soak; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-bash tools/refresh_profiles.sh r03 gpurun_out/prof > $O/refresh.log 2>&1; tail -8 $O/refresh.log
 S=$O/r03_soak.txt; : > $S
 {
 echo "# repeatability soaks on the round-3 build (one MI355X); every line is a tool's own summary"
@@ -22,6 +21,24 @@ done; done
 unset DR_STACK_FL
 echo "# --T 250 --B 8 --reps 40 (64-frame flavour)"; timeout 600 python tools/xcd_stress.py --T 250 --B 8 --reps 40 2>&1 | tail -2
 echo "# --T 500 --chain 20 --reps 10 (whole chains, tail kernel)"; timeout 900 python tools/xcd_stress.py --T 500 --B 4 --chain 20 --reps 10 2>&1 | tail -2
+echo "## part-filled launches (split-K beyond one resident round): whole captured chains twice, bitwise"
+timeout 600 python - <<'PY'
+import sys, torch
+sys.path.insert(0, ".")
+import bench
+dev = torch.device("cuda", 0)
+hp = dict(bench.HP); hp.update(timesteps=20)
+m = bench.build_model(dev, hp=hp, sampler="cfdg_ddpm_x0")
+g = torch.Generator().manual_seed(21)
+bad = 0; n = 0
+for B, T in ((3, 125), (5, 125), (6, 125), (10, 125), (12, 125), (20, 125), (1, 640), (2, 640), (2, 320)):
+    wav = (0.1 * torch.randn(B, T * 512, generator=g)).to(dev); x = torch.randn(B, 1, T, 88, generator=g).to(dev)
+    ref = m.sample(x, wav, seed=4)[0].clone()
+    for rep in range(4):
+        m._fe_key = None
+        n += 1; bad += int(not torch.equal(m.sample(x, wav, seed=4)[0], ref))
+print(f"part-filled chains: {n} repeats of 9 geometries, {bad} differ; fallbacks {m.engine.fallbacks}")
+PY
 echo "# --T 125 --B 9 --reps 40 (padded launch, 9 guided clips)"; timeout 600 python tools/xcd_stress.py --T 125 --B 9 --reps 40 2>&1 | tail -2
 } >> $S 2>&1
 cat $S
