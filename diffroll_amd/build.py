@@ -14,8 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffroll_amd.so")
-SOURCES = ["kernels.hip", "engine.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "kernels.h"), os.path.join(os.path.dirname(HERE), "include", "diffroll_amd.h")]
+# one translation unit per kernel family (a kernel edit rebuilds its unit only; the units compile in parallel)
+SOURCES = ["gemm.hip", "stack.hip", "tail.hip", "update.hip", "frontend.hip", "engine.hip", "comm.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "device_common.h", "gemm_body.h", "persistent.h", "update_quad.h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", "diffroll_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -40,7 +42,12 @@ VARIANTS = {
     #   asan:   the HOST side (engine.hip, comm.hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
     #           UndefinedBehaviorSanitizer; device code is compiled as usual (-fno-gpu-sanitize)
     "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
-    "ablate1": dict(flags=["-DDR_ABLATE=1"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments
+    "ablate1": dict(flags=["-DDR_ABLATE=1"], link=[]),
+    # A/B builds of the conv K loop (round 4): the rounds 1-3 loop (one chain per output, two weight-fragment sets) /
+    # blocked accumulation off, in-place fragments on / blocked accumulation with two fragment sets
+    "r3loop": dict(flags=["-DDR_FOLD=0", "-DDR_AINPLACE=0"], link=[]),
+    "nofold": dict(flags=["-DDR_FOLD=0"], link=[]),
+    "twosets": dict(flags=["-DDR_AINPLACE=0"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments
     "asan": dict(flags=["-O1", "-g", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"],
                  link=["-fsanitize=address,undefined", "-shared-libsan"]),
     #   ubsan:  the host side under UndefinedBehaviorSanitizer alone (-fno-sanitize-recover: the first finding aborts).
@@ -65,16 +72,23 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     lib = variant_path(variant) if variant else LIB
     objs = []
     relink = force
+    jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + extra["flags"] + ["-c", s, "-o", o]
+            jobs.append([hipcc] + FLAGS + extra["flags"] + ["-c", s, "-o", o])
+        objs.append(o)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            relink = True
-        objs.append(o)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+            list(ex.map(run, jobs))
+        relink = True
     if relink or _stale(lib, objs):
         link = []
         for f in extra["link"]:

@@ -259,7 +259,7 @@ std::vector<uint16_t> pack_weights_s3(int MT, int kchunks, int taps, F get) {
 }
 
 // paired row map: packed row -> (which half mi, channel c); a 128-row tile = 4 consumer waves x
-// [16 gate (cos) rows, 16 filter (sin) rows] of the same 16 channels (kernels.hip: pairing inside one MFMA tile)
+// [16 gate (cos) rows, 16 filter (sin) rows] of the same 16 channels (gemm_body.h: pairing inside one MFMA tile)
 inline void paired_row(int prow, int& mi, int& c) {
     const int mt = prow >> 7, rr = prow & 127;
     const int w = rr >> 5, r = rr & 31;
@@ -374,6 +374,13 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
     };
     if (forced && strlen(forced) >= 4) {
         const int ff = forced[0] == '1' ? 1 : 0, fn = atoi(forced + 3);
+        // "32:4": half tiles (64 packed rows x 128 frames, in-block K split) for the fp32 gated conv, else 128-frame tiles
+        if (ff == 0 && fn == 4) {
+            const bool ok = prec == 0 && epi == EPI_GATE && taps > 1 && allow16 && (MT % 1 == 0) &&
+                            2 * gemm_lds_bytes(2, 1, taps, dil, 0, EPI_GATE) <= 160 * 1024;
+            if (ok) return Tile{0, 4};
+            if (feasible(cands[0])) return Tile{0, 2};
+        }
         for (const Cand& c : cands)
             if (c.flavor == ff && c.n == fn && feasible(c)) return Tile{ff, fn};
     }
@@ -552,11 +559,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
-        // Flavours 1 / 2 (64 / 128-frame blocks) are chosen automatically.  Flavour 5 (160-frame blocks on the 16x16x4
-        // MFMA: what fits BASELINE config 5's 640-frame clips into one resident round) exists and is bit-identical,
-        // but measured 0.5 % SLOWER than the per-phase launches there (1806 vs 1796 ms per chain: 554-us conv phases
-        // gain nothing from losing a 9-us launch, and the merged kernel spills outside its loops) - it only runs when
-        // DR_STACK_FL=5 asks for it (tests / measurements).
+        // Flavours 1 / 2 (128 packed rows x 64 / 128 frames per block) and 4 (half tiles: 64 rows x 128 frames, K split
+        // over the block's wave pairs) are chosen automatically; DR_STACK_FL=n pins one (tests / measurements).
         static const int fl_force = getenv("DR_STACK_FL") ? atoi(getenv("DR_STACK_FL")) : 0;
         // A launch must be ONE resident round (groups spin on each other), so an evaluation with more samples than
         // fit is launched in balanced CHUNKS of samples, one fused launch after the other (samples are independent).
@@ -578,17 +582,20 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             return best;
         };
         double best = 1e30;
-        for (int fl : {1, 2, 5}) {
-            if (fl_force ? fl != fl_force : fl == 5) continue;
+        static const double half_pen = getenv("DR_STACK_HALF_PEN") ? atof(getenv("DR_STACK_HALF_PEN")) : 1.03;
+        for (int fl : {1, 2, 4}) {
+            if (fl_force && fl != fl_force) continue;
             const int bn = stack_tile_frames(fl);
-            const long gsize = (long)MT * ((T + bn - 1) / bn);                          // blocks per sample
+            const long gsize = stack_group_blocks(fl, Cp, T);                           // blocks per sample
             const long cap = std::min<long>(e->n_cus, 1024) / gsize;                    // samples per launch
             if (cap < 1 || stack_lds_bytes(fl, e->K, maxdil) > 160 * 1024) continue;
             const long chunks = (NB + cap - 1) / cap;
             if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
-            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : (fl == 5 ? 1.04 : 1.0));
+            // (a half tile is half the rows of the others' blocks: it costs like 64 frames of a 128-row block, at the
+            // 128-frame flavour's pace plus the in-block exchange)
+            const double cost = (1.0 - 0.025 / chunks) * chunks * (fl == 4 ? 64 * half_pen : bn * (fl == 1 ? 1.0 / 0.93 : 1.0));
             // (a single launch that leaves more than a fifth of the CUs idle is better served by the per-phase kernels'
             // split-K, which this cost model does not see: they cut the same work into many short blocks that balance
             // over all CUs - 8 evaluations x 125 frames (half the chip): 1365 vs 2422 us per step, 10 / 12 evaluations
@@ -602,7 +609,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         // fused step (option "fused_tail"): everything behind the stack launch - skip / output projection, update, and
         // for a chain the next step's input projection and (guided) shared first-layer conv - is one tail launch,
         // when the evaluation is ONE fused launch of the 32x32-MFMA flavours
-        fused_step = stack_ni && stack_ni != 5 && stack_chunks == 1 && e->opt_tail && !tsel;
+        fused_step = stack_ni && stack_chunks == 1 && e->opt_tail && !tsel;
     }
     const bool use_tail = fused_step && tail != nullptr;
     // input projection + relu (model/diffwave.py:667-668) - unless the previous step's tail kernel already wrote h / hd
@@ -747,7 +754,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (use_tail) {
         // the rest of the step in one launch: skip projection, output projection, combine + update, next input projection
         TailArgs ta{};
-        ta.NB = NB; ta.T = T; ta.Cp = Cp; ta.BN = stack_tile_frames(stack_ni);
+        // (grouping of the tail launch: half tiles have 2 MT blocks per 128-frame tile - the tail takes the 64-frame
+        // grouping, MT blocks per 64-frame tile, which never needs more blocks than the stack launch had)
+        ta.NB = NB; ta.T = T; ta.Cp = Cp; ta.BN = stack_ni == 4 ? 64 : stack_tile_frames(stack_ni);
         ta.dual = (bmod > 0 && NB == 2 * bmod) ? bmod : 0;
         ta.u_B = tail->u_B;
         ta.xcd_n = e->opt_stack_xcd; ta.fault = e->opt_stack_fault;

@@ -1,4 +1,4 @@
-// Internal launch interface between engine.hip (host logic, C-ABI) and kernels.hip (gfx950 kernels).
+// Internal launch interface between engine.hip (host logic, C-ABI) and the kernel translation units gemm / stack / tail / update / frontend .hip (gfx950 kernels).
 // Not part of the public ABI (that is include/diffroll_amd.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -96,6 +96,8 @@ hipError_t init_kernels();
 hipError_t read_bounds(unsigned long long* out4);
 hipError_t reset_bounds();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
+// NI = 1 / 2: blocks of 128 packed rows x 64 / 128 frames; NI = 4 (fp32 EPI_GATE only): HALF tiles of 64 packed rows x
+// 128 frames, K split over the block's wave pairs (gemm_body.h, SK2)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
 // flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
 hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
@@ -111,7 +113,7 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 // one launch per phase.  grid = (samples x frame tiles x M tiles) <= the number of CUs, every block owns the same
 // (M tile, frame tile) in every phase; the blocks of one sample (= one clip evaluation: M tiles x its frame tiles)
 // form a GROUP that synchronises on a device counter between phases - nothing is exchanged between groups, so
-// there is no grid-wide barrier.  See stack_kernel in kernels.hip.
+// there is no grid-wide barrier.  See stack_kernel in stack.hip.
 // ---------------------------------------------------------------------------------------------
 constexpr int DR_STACK_MAX_LAYERS = 30;
 struct StackLayer {
@@ -144,10 +146,12 @@ struct StackArgs {
     long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
     StackLayer layer[DR_STACK_MAX_LAYERS];
 };
-// FL = frame-tile flavour: 1 / 2 = 64 / 128 frames per block (32x32x2 MFMA), 5 = 160 frames (16x16x4 MFMA).  The
-// caller guarantees NB * ceil(T / stack_tile_frames(FL)) * (Cp / 64) <= #CUs and stack_lds_bytes(..) <= 160 KiB.
+// FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames, 4 = half tiles of 64 packed rows x 128 frames (K split
+// over the block's wave pairs).  The caller guarantees NB * stack_group_blocks(FL, Cp, T) <= #CUs and
+// stack_lds_bytes(..) <= 160 KiB.
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st);
 int stack_tile_frames(int FL);
+int stack_group_blocks(int FL, int Cp, int T);      // blocks per clip evaluation
 size_t stack_lds_bytes(int FL, int taps, int max_dil);
 
 // Per-call scalars of the update that must not be baked into a captured graph: the chain graph reads them from
@@ -177,7 +181,7 @@ struct UpdateArgs {
 };
 hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
 
-// Tail of a reverse step as one persistent launch (tail_kernel in kernels.hip): skip projection -> output projection ->
+// Tail of a reverse step as one persistent launch (tail_kernel in tail.hip): skip projection -> output projection ->
 // classifier-free combine + posterior update -> input projection of the next step.  Same grid / grouping as the
 // stack_kernel launch it follows: NB samples (first `dual` conditional, next `dual` unconditional when dual > 0) x
 // ceil(T / BN) frame tiles x Cp / 64 blocks, all resident at once.

@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_fused.py: runs every case of one frame-tile width with the per-phase kernels
+"""Child process of tests/test_gpu_fused.py: runs every case of one block flavour with the per-phase kernels
 pinned (by the tuning overrides, which are read once per process) to the SAME kernel flavours the fused kernel
 is built from - 32x32 MFMA conv tiles of that width, no split-K, the direct-from-L2 1x1 - so that fused and
 per-phase results must agree bit for bit.  Prints one JSON line."""
@@ -36,10 +36,14 @@ CASES = {
         (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
         (512, 2, 9, 32, 125, "cfdg_ddpm_x0"),       # 64 evaluations: two fused launches (all conditional / all unconditional)
     ],
-    5: [  # 160-frame blocks on the 16x16x4 MFMA (DR_STACK_FL=5: measured slower than per-phase launches, kept tested)
-        (512, 2, 15, 4, 640, "cfdg_ddpm_x0"),       # BASELINE config 5 per-GPU geometry: 8 evaluations x 4 tiles x 8 M tiles
-        (512, 2, 9, 6, 300, "generation_ddpm_x0"),  # ragged second tile, 1x1 as a 96- and a 64-frame pass
-        (192, 3, 9, 3, 161, "ddpm_x0"),             # one frame in the second tile; M tile straddling the halves
+    4: [  # half tiles: 64 packed rows x 128 frames, K split over the block's wave pairs (DR_STACK_FL=4, DR_TILE=32:4)
+        (512, 2, 9, 16, 125, "generation_ddpm_x0"),  # BASELINE config 3 per-GPU geometry: 16 evaluations x 16 half tiles = 256 blocks
+        (512, 3, 9, 8, 125, "cfdg_ddpm_x0"),        # guided: the shared first-layer conv stays a 128-row launch / tail part T4
+        (512, 2, 15, 4, 250, "cfdg_ddpm_x0"),       # k = 15 (halo 56), two frame tiles per clip: 8 evaluations x 32 blocks
+        (192, 3, 9, 5, 129, "ddpm_x0"),             # 6 half tiles, one straddling nothing but M tile 1 holding residual AND skip rows; 1 frame in tile 2
+        (64, 3, 9, 3, 40, "cfdg_ddpm_x0"),          # one M tile: half 0 = all residual rows, half 1 = all skip rows; one chunk per K half
+        (128, 2, 3, 8, 65, "generation_ddpm_x0"),   # k = 3, 8 groups (group-per-XCD mapping)
+        (512, 2, 9, 20, 125, "ddpm_x0"),            # 20 evaluations x 16 blocks: two fused launches of 10 samples
     ],
 }
 

@@ -156,5 +156,8 @@ def test_checker_build_variants_are_declared():
     assert "-DDR_BOUNDS" in build.VARIANTS["bounds"]["flags"]
     assert any("-fsanitize=address" in f for f in build.VARIANTS["asan"]["flags"])
     assert build.variant_path("bounds").endswith("libdiffroll_amd_bounds.so")
-    src = open(os.path.join(ROOT, "diffroll_amd", "csrc", "kernels.hip")).read()
+    csrc = os.path.join(ROOT, "diffroll_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".h")))
     assert src.count("DR_CHECK_LDS(") >= 12 and "check_gemm_extents" in src      # the instrumentation is there
+    for unit in ("gemm", "stack", "tail"):                                       # ... in every unit that carries checks
+        assert f"DR_BOUNDS_TU({unit})" in src

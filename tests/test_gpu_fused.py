@@ -36,15 +36,13 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", [1, 2, 5])
+@pytest.mark.parametrize("ni", [1, 2, 4])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
-    """All cases of tests/fused_cases.py for one frame-tile width, in a child process whose per-phase kernels are
+    """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
     pinned to the flavours the fused kernel is built from (the overrides are read once per process)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni))
-    if ni == 5:      # the 160-frame flavour: 16x16 MFMA conv tiles, 1x1 with 5 frame tiles per wave; only on request
-        env.update(DR_TILE="16:5", DR_PW_NW="5", DR_STACK_FL="5")
+    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni if ni < 4 else 4), DR_STACK_FL=str(ni))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -55,11 +53,11 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
             assert run["timed_out"] == 0 and run["launches"] >= 1, rec
             assert run["kernel"] == f"stack_kernel<{ni}>", rec
             assert run["equal"], rec
-            if run.get("chain"):      # whole chains: the tail kernel ran (or, switched off / 160-frame flavour, did not)
+            if run.get("chain"):      # whole chains: the tail kernel ran (or, switched off, did not)
                 # (an evaluation that needs several fused launches - sample chunks - keeps the separate tail launches)
                 # (DR_TAIL=0 - a forced-mode run of the suite - only changes the DEFAULT: runs that set the option carry "tail")
                 env_off = "tail" not in run and os.environ.get("DR_TAIL", "1") == "0"
-                want_tail = ni != 5 and run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1 and not env_off
+                want_tail = run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1 and not env_off
                 assert (run["tail_launches"] >= 1) == want_tail, rec
 
 
@@ -142,23 +140,46 @@ def test_fused_stack_soak_under_uneven_load():
 # kernels - is covered by tests/test_gpu_r3.py)
 
 
-@pytest.mark.parametrize("flavour,args", [("5", ["--T", "640", "--reps", "40"]), ("", ["--T", "500", "--reps", "24"]),
-                                          ("", ["--T", "250", "--reps", "24"]),
-                                          ("", ["--T", "500", "--chain", "6", "--reps", "16"])])     # chains: the tail kernel too
+@pytest.mark.parametrize("flavour,args", [("4", ["--T", "500", "--B", "2", "--reps", "200"]),
+                                          ("2", ["--T", "500", "--reps", "200"]),
+                                          ("1", ["--T", "250", "--reps", "200"]),
+                                          ("2", ["--T", "500", "--chain", "6", "--reps", "40"]),     # chains: the tail kernel too
+                                          ("4", ["--T", "250", "--B", "4", "--chain", "6", "--reps", "40"])])
 def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
-    """tools/xcd_stress.py: the full-depth (15-layer) full-width net with 32-block groups, block mapping 0 (every group
-    spread over all eight XCDs: every hand-off crosses XCDs, and the X tiles of a conv phase arrive from memory instead
-    of the local L2) against mapping 1, bit for bit, repeatedly - the 160-frame flavour (DR_STACK_FL=5: this is the
-    geometry that exposed the missing wait before the LDS-DMA hand-over barrier, 25 % of the runs) and the 128- / 64-frame
-    ones."""
+    """tools/xcd_stress.py: the full-depth (15-layer) full-width net with 32- / 64-block groups, block mapping 0 (every
+    group spread over all eight XCDs: every hand-off crosses XCDs, and the X tiles of a conv phase arrive from memory
+    instead of the local L2) against mapping 1, bit for bit, >= 200 persistent launches per flavour (the half-tile,
+    128- and 64-frame ones; whole chains bring the tail kernel in).  This is the class of test that exposed the missing
+    wait before the LDS-DMA hand-over barrier in round 3 (25 % of the runs of the then 160-frame flavour)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    if flavour:
-        env["DR_STACK_FL"] = flavour
+    env = dict(os.environ, DR_STACK_FL=flavour)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "xcd_stress.py")] + args, env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
     assert "RESULT ok" in r.stdout, r.stdout[-2000:]
-    want = f"stack_kernel<{flavour or ('2' if '500' in args else '1')}>"
-    assert want in r.stdout, r.stdout[-500:]
+    assert f"stack_kernel<{flavour}>" in r.stdout, r.stdout[-500:]
+
+
+def test_fused_chain_soak_is_bitwise_repeatable_at_the_bench_geometries():
+    """tools/fused_soak.py: 6 captured 200-step chains each at BASELINE config 2 (128-frame blocks) and config 3 (half
+    tiles) - 2 x 1200 fused + tail launches - must give bit-identical rolls, without a barrier time-out."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in ("2", "3"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_soak.py"), "--chains", "6", "--config", cfg],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (cfg, r.stdout[-1500:], r.stderr[-2000:])
+        assert "mismatching chains 0, barrier time-outs 0" in r.stdout, r.stdout[-1000:]
+
+
+def test_split_k_determinism_soak():
+    """tools/determinism_soak.py: 64 shape / seed / precision combinations of small launches (split-K through the
+    workspace: write-through partials, tickets, the last arriver's ordered re-read), every 10-step chain run twice with
+    the same seed: bit-identical."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_soak.py"), "64"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    assert "every chain bitwise repeatable" in r.stdout, r.stdout[-500:]

@@ -4,7 +4,7 @@ in the ISSUING wave, by `s_waitcnt vmcnt(0)` after its last `buffer_load ... lds
 (MI355X_MICROARCH.md "Two waves per SIMD", item 7) and hipcc does not always insert the wait for a `__syncthreads()`
 behind LDS-DMA builtins (it treats them as loads without a register result).
 
-For every kernel of csrc/kernels.hip: walk the control-flow graph of the gfx950 assembly from every LDS-DMA load and
+For every kernel of csrc/{gemm,stack,tail}.hip: walk the control-flow graph of the gfx950 assembly from every LDS-DMA load and
 report any path that reaches an s_barrier (or the end of the kernel) without passing `s_waitcnt vmcnt(0)`.
 
     python tools/isa_audit.py [--defines -DDR_BOUNDS]        (exit code 1 when a path is found)
@@ -19,12 +19,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MAX_DIST = 100
 
 
-def compile_asm(extra):
-    out = os.path.join(tempfile.mkdtemp(), "kernels.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
-           os.path.join(ROOT, "diffroll_amd", "csrc", "kernels.hip"), "-o", out] + extra
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
-    return open(out).read()
+CSRC = os.path.join(ROOT, "diffroll_amd", "csrc")
+DEVICE_UNITS = ("gemm.hip", "stack.hip", "tail.hip")        # the translation units that hold LDS-DMA producers
+
+
+def compile_asm(extra, units=DEVICE_UNITS):
+    """gfx950 assembly of the kernel translation units (device code only), concatenated."""
+    txt = []
+    for u in units:
+        out = os.path.join(tempfile.mkdtemp(), u + ".s")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+               os.path.join(CSRC, u), "-o", out] + extra
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        txt.append(open(out).read())
+    return "\n".join(txt)
 
 
 def kernels(txt):
