@@ -150,6 +150,35 @@ def chain_bytes(cfg, T):
     return cfg["S"] * (cfg["evals"] * w_bytes + cfg["B"] * T * (per_frame + 3 * M * 4))
 
 
+def cold_start(configs=(1, 2)):
+    """Time-to-first-roll of a one-shot process (the reference's product: sampling.py:22-73 loads a checkpoint and runs ONE
+    trainer.predict): `python -m diffroll_amd.coldstart --config N` in a FRESH process per configuration - engine creation,
+    dr_commit (packing / uploads / tables), the first sample (front-end + graph capture + instantiate + chain) and the steady
+    chain next to them.  Runs after the timed region, on the same device (this process is idle meanwhile)."""
+    import subprocess
+    out = {}
+    for c in configs:
+        try:
+            r = subprocess.run([sys.executable, "-m", "diffroll_amd.coldstart", "--config", str(c), "--json"], cwd=ROOT,
+                               capture_output=True, text=True, timeout=300)
+            line = next(ln for ln in r.stdout.splitlines() if ln.startswith("COLD_START "))
+            j = json.loads(line[len("COLD_START "):])
+            out[f"config{c}"] = {
+                "create_s": round(j["create_s"], 3),
+                "commit_s": round(j["commit_s"]["total_incl_param_copies"], 3),
+                "commit_split_s": {k: round(v, 3) for k, v in j["commit_s"].items() if k != "total_incl_param_copies"},
+                "first_sample_s": round(j["first_sample_s"], 3),
+                "capture_instantiate_s": round(j["capture_instantiate_s"], 3), "graph_nodes": j["graph_nodes"],
+                "steady_ms": round(j["steady_ms"], 2),
+                "import_torch_s": round(j["import_torch_s"], 2), "hip_init_s": round(j["hip_init_s"], 2),
+                "host_model_s": round(j["host_model_s"], 2),
+                "process_start_to_first_roll_s": round(j["process_start_to_first_roll_s"], 2) if j.get("process_start_to_first_roll_s") else None,
+            }
+        except Exception as ex:       # noqa: BLE001 - reported, never allowed to fail the measurement
+            out[f"config{c}"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+    return out
+
+
 def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
     """The oracle (CPU port of the reference arithmetic) on this box's host cores, bounded sample."""
     from oracle import diffroll_ref as R           # checker / baseline only - never the product path
@@ -236,6 +265,7 @@ def main():
                     help="multi-rank runs: also create a C-ABI communicator (dr_comm_create) and compare dr_gather with "
                          "torch's all-gather (always done in 1-rank groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the time-to-first-roll subprocesses (configs 1 and 2)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
     args = ap.parse_args()
@@ -432,6 +462,8 @@ def main():
             result["dr_gather_check"] = check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(model, cfg, hp)
+    if rank == 0 and world == 1 and not args.no_cold_start:
+        result["cold_start"] = cold_start()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

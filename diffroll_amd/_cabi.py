@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 7
+DR_ABI_VERSION = 8
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME, DR_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 
 SAMPLERS = {
@@ -38,6 +38,7 @@ EXPORTS = [
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
     "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
     "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds", "dr_tail_launches",
+    "dr_pending_timeout", "dr_cold_times",
 ]
 
 
@@ -111,6 +112,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_stack_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.dr_tail_launches.restype = C.c_int
     lib.dr_tail_launches.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.dr_pending_timeout.restype = C.c_int
+    lib.dr_pending_timeout.argtypes = [vp, vp]
+    lib.dr_cold_times.restype = C.c_int
+    lib.dr_cold_times.argtypes = [vp, C.POINTER(C.c_double)]
     lib.dr_frame_counts.restype = C.c_int
     lib.dr_frame_counts.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.POINTER(C.c_int64), vp]
     lib.dr_note_runs.restype = C.c_int

@@ -150,8 +150,14 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
             raise SystemExit(launch.spawn_ranks(gpus, spec.name, list(sys.argv[1:]), module=True))
         raise SystemExit(launch.spawn_ranks(gpus, os.path.abspath(sys.argv[0]), list(sys.argv[1:])))
     rank, world, local_rank = launch.rank_env()
-    if launch.under_launcher() and world != gpus:
-        raise SystemExit(f"gpus={gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if launch.under_launcher():
+        # Trainer(gpus=N) counts devices PER NODE (sampling.py:70): compare with the launcher's ranks on THIS node, and
+        # only when gpus= was given - an explicitly launched job is authoritative over the default gpus=1 (ADVICE r3:
+        # `torchrun --nproc-per-node 8 sampling.py ...` and multi-node jobs must not be rejected)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        explicit = any(a.split("=", 1)[0] == "gpus" for a in (sys.argv[1:] if argv is None else argv))
+        if explicit and local_world != gpus:
+            raise SystemExit(f"gpus={gpus} but the launcher started {local_world} rank(s) on this node (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = launch.init_process_group(device) if world > 1 else None

@@ -126,8 +126,10 @@ int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank) {
 }
 
 int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, int B_local, int T, void* stream) {
-    (void)e;                                    // no engine state is involved; kept for a uniform call shape
     if (!comm || !d_shard || !d_full) return cfail(DR_EINVAL, "null argument");
+    // the one piece of engine state that matters here: a roll produced by a fused launch that timed out must not be
+    // gathered (include/diffroll_amd.h: dr_finish); `e` may be NULL
+    if (e && dr_pending_timeout(e, stream) != DR_OK) return cfail(DR_ETIMEOUT, dr_last_error(e));
     if (B_local < 0 || T <= 0) return cfail(DR_EINVAL, "bad shape");
     if (B_local == 0) return DR_OK;
     int prev = -1;

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/diffroll_amd.h"
@@ -84,6 +86,8 @@ struct dr_engine {
     float* xwork = nullptr;                // the captured chain runs in place on this engine-owned roll buffer
     float *hd3 = nullptr, *g3 = nullptr;   // split-bf16 (S3) versions of hd and g: 1.5x the fp32 size
     int prec = 0;                          // 0: exact fp32 MFMA, 1: split-bf16 (bf16x3, 6 products)
+    bool s3_ready = false;                 // the split-bf16 packings exist (built on first use: ensure_s3)
+    double t_pack_s = 0.0, t_upload_s = 0.0, t_tables_s = 0.0, t_capture_s = 0.0;      // dr_cold_times
     int norm_framewise = 0;                // spectrogram normalisation: 0 imagewise, 1 framewise (norm_args[2])
     // conditioner tensors of the last dr_frontend: [L][fe_B][2Cp/4][fe_T][4]
     int fe_B = 0, fe_T = 0;
@@ -121,7 +125,6 @@ struct dr_engine {
     volatile unsigned* stack_err_host = nullptr;
     unsigned* stack_derr = nullptr;     // the same flag in device memory (what the kernels poll / test at launch start)
     unsigned* stack_xid = nullptr;      // [1024] (generation, XCC id) tags published by the blocks of the last launch
-    unsigned* stack_pbar = nullptr;     // [STACK_GROUPS][4] pair counters of the shared phase 0 (classifier-free guidance)
     unsigned* tail_bar = nullptr;       // group / pair counters of the tail kernel (own arrays, same protocol)
     unsigned* tail_pbar = nullptr;
     int opt_tail = 1;                   // fused step: layer 0's shared conv inside the stack launch + the tail kernel
@@ -129,6 +132,11 @@ struct dr_engine {
     float* xalt = nullptr;              // the tail kernel writes x_{t-1} here (it must not update x_t in place: other
                                         // blocks still read it); the chain ping-pongs between this and its roll buffer
     int64_t stack_fallbacks = 0;        // time-outs detected by dr_finish: each one switched this engine to per-phase launches
+    bool unverified = false;            // persistent launches have been issued since the last check of the time-out flag
+    int opt_blocked = 1;                // option "blocked_accumulation": 1 = where it is free, 2 = in the 128-frame flavours too
+    int opt_rearm = 0;                  // option "fused_rearm": clean chains after a time-out before fusing again (0: never)
+    int healed_from = 0;                // the fused_stack value a time-out switched off (0: none pending re-arm)
+    int clean_chains = 0;               // chains finished cleanly since that time-out
     float* xsave = nullptr;             // dr_sample_checked: copy of x_T, so that a timed-out chain can be re-run
     size_t xsave_cap = 0;
     long long* stack_dbg = nullptr;     // phase tick marks of block 0 (dr_debug_stack_ticks)
@@ -167,6 +175,23 @@ int fail(dr_engine* e, int code, const char* fmt, ...) {
     } while (0)
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Host-side packing of the layers is embarrassingly parallel (one task per residual layer): dr_commit is on the
+// critical path of a one-shot process (sampling.py: load checkpoint -> one batch), where it used to cost more than
+// the whole 50-step chain of a single clip.  DR_PACK_THREADS caps the worker count (1 = serial).
+template <class F>
+void parallel_for(int n, F fn) {
+    static const int cap = getenv("DR_PACK_THREADS") ? atoi(getenv("DR_PACK_THREADS")) : 16;
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nt = std::max(1, std::min(std::min(n, cap), hw > 0 ? hw : 1));
+    if (nt == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); });
+    for (auto& t : th) t.join();
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Every entry point runs on the engine's device and leaves the caller's current device as it found it (a process
 // that drives several GPUs must not have its device switched by constructing or calling an engine).
@@ -347,17 +372,12 @@ struct Tile { int flavor, n; };
 // the 16x16 kernel, which has no split.  Cost in the units of pick_tile (block rounds x frames per block x penalty) of
 // the best split that needs MORE than one resident round, with a 5 % handicap; 1e30 if there is none.
 double split_cost(long blocks, int bn, double pen, int MT, int taps) {
-    static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;
-    static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 2048;
-    const int nchunks = 2 * MT;                                                  // 32-channel chunks of K
-    const double us_per_frame = nchunks * taps * 16.0 * (bn / 32) * 69.0 / 2400.0 / bn;
-    double best = 1e30;
-    for (int ks = 2; ks <= ks_max && ks <= 16 && blocks * ks <= max_blocks && nchunks % ks == 0 &&
-                     (size_t)blocks * ks * 128 * bn <= dr_engine::SK_WS_FLOATS; ks *= 2) {
-        if (blocks * ks <= 256) continue;                                        // (one resident round: the launcher's own business)
-        best = std::min(best, 1.05 * ((double)((blocks * ks + 255) / 256) / ks * bn * pen + (4.0 + ks) / us_per_frame));
-    }
-    return best;
+    const int nchunks = 2 * MT;                                                  // 32-channel chunks of K (convs: KS = 1)
+    // the launcher's own decision and price (plan_ksplit, gemm.hip): what it WILL do with this launch
+    const KSplitPlan p = plan_ksplit(blocks, nchunks, nchunks, taps, bn / 64, 0, dr_engine::SK_WS_FLOATS, dr_engine::SK_CNT_N);
+    if (p.ks <= 1 || blocks * p.ks <= 256) return 1e30;                          // (one resident round: priced by the caller)
+    const double us_per_frame = p.us_unsplit / ((double)((blocks + 255) / 256) * bn);      // us of one frame column of a full-K tile
+    return 1.05 * pen * p.us / us_per_frame;
 }
 Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool allow16) {
     static const char* forced = getenv("DR_TILE");     // tuning experiments: "32:2", "16:5", ... (if it fits)
@@ -379,7 +399,7 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
             const bool ok = prec == 0 && epi == EPI_GATE && taps > 1 && allow16 && (MT % 1 == 0) &&
                             2 * gemm_lds_bytes(2, 1, taps, dil, 0, EPI_GATE) <= 160 * 1024;
             if (ok) return Tile{0, 4};
-            if (feasible(cands[0])) return Tile{0, 2};
+            if (feasible(cands[3])) return Tile{0, 1};      // (the shared first-layer conv: 64-frame blocks accumulate blocked, as half tiles do)
         }
         for (const Cand& c : cands)
             if (c.flavor == ff && c.n == fn && feasible(c)) return Tile{ff, fn};
@@ -647,6 +667,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             sa.xcd_n = e->opt_stack_xcd;
             sa.warm = e->opt_stack_warm;
             sa.fault = e->opt_stack_fault;
+            sa.fold128 = e->opt_blocked >= 2;
             sa.bar = e->stack_bar; sa.err = e->stack_err; sa.derr = e->stack_derr; sa.xid = e->stack_xid;
             sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
             for (int l = 0; l < L; ++l) {
@@ -666,6 +687,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
             HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
             e->stack_launches += 1;
+            e->unverified = true;
             if (timed) {
                 HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used++].second, st));
                 const double C = e->C, fr = (double)nb * T;
@@ -675,7 +697,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 e->prof_name = "stack_kernel<" + std::to_string(stack_ni) + "> (fused residual stack: dilated conv k=" +
                                std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
                                std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) +
-                               (stack_chunks > 1 ? ", " + std::to_string(stack_chunks) + " sample chunks" : "") + ")";
+                               (stack_chunks > 1 ? ", " + std::to_string(stack_chunks) + " sample chunks" : "") +
+                               ((stack_ni != 2 || e->opt_blocked >= 2) ? ", blocked accumulation" : ", one fp32 chain per output") + ")";
             }
             b0 += nb;
         }
@@ -697,6 +720,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 a.bias2 = w.conv_b;
             }
             a.taps = e->K; a.dil = w.dil;
+            a.fold128 = e->opt_blocked >= 2;
             a.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T : e->cond_dummy;
             a.c_bs = (long)2 * Cp * T;
             a.n_cond = n_cond;
@@ -775,6 +799,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 ta.cond = e->cond ? e->cond : e->cond_dummy;
                 ta.c_bs = (long)2 * Cp * T;
                 ta.taps = e->K; ta.dil = w0.dil;
+                ta.fold = (stack_ni != 2 || e->opt_blocked >= 2);
                 ta.g = e->g;
             }
         }
@@ -783,6 +808,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         ta.dbg = (e->stack_dbg_on && tail->next_t >= 0) ? e->stack_dbg + 112 : nullptr;
         HIPCHK(e, launch_tail(ta, st));
         e->tail_launches += 1;
+        e->unverified = true;
         tail->done = true;
         tail->inproj_done = tail->next_t >= 0;
         return DR_OK;
@@ -862,7 +888,7 @@ int run_step(dr_engine* e, int sampler, float* x, const float* noise, int B, int
 
 // After a barrier time-out (device idle): re-arm the group counters, forget the published XCC tags, lower both flags.
 int clear_stack_timeout(dr_engine* e) {
-    HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(16 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));    // all four counter arrays
+    HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(12 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));    // all three counter arrays
     HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));
     HIPCHK(e, hipMemset(e->stack_derr, 0, 16 * sizeof(unsigned)));
     *e->stack_err_host = 0;
@@ -873,6 +899,38 @@ void drop_graph(dr_engine* e) {
     if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     e->gkey = GraphKey{};
+}
+
+// The split-bf16 ("S3") packings of the two hot GEMMs (same row maps and zero padding as the fp32 ones): only the opt-in
+// precision reads them, so they are built on first use - at dr_set_precision(BF16X3) after a commit, or at the end of a
+// commit made in that mode - instead of costing every start-up 0.4 s of packing and 520 MB of uploads.
+int ensure_s3(dr_engine* e) {
+    if (e->s3_ready || !e->committed) return DR_OK;
+    const int C = e->C, Cp = e->Cp, L = e->L, K = e->K;
+    std::vector<std::vector<uint16_t>> c3(L), o3(L);
+    parallel_for(L, [&](int l) {
+        const std::string pre = "residual_layers." + std::to_string(l) + ".";
+        const auto& Wd = *find_param(e, pre + "dilated_conv.weight");
+        const auto& Wo = *find_param(e, pre + "output_projection.weight");
+        const int MTc = Cp / 64;
+        c3[l] = pack_weights_s3(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
+            int mi, c; paired_row(pr, mi, c);
+            return (c < C && ch < C) ? Wd[((size_t)(mi * C + c) * C + ch) * K + j] : 0.f;
+        });
+        o3[l] = pack_weights_s3(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
+            const int half = pr >= Cp, c = pr - half * Cp;
+            return (c < C && ch < C) ? Wo[(size_t)(half * C + c) * C + ch] : 0.f;
+        });
+    });
+    for (int l = 0; l < L; ++l) {
+        int rc;
+        if ((rc = upload_bytes(e, c3[l].data(), c3[l].size() * 2, &e->layers[l].conv_w3)) ||
+            (rc = upload_bytes(e, o3[l].data(), o3[l].size() * 2, &e->layers[l].out_w3)))
+            return rc;
+        c3[l] = {}; o3[l] = {};
+    }
+    e->s3_ready = true;
+    return DR_OK;
 }
 
 int check_ready(dr_engine* e, int sampler, int B, int T) {
@@ -944,6 +1002,7 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
     if (const char* v = getenv("DR_STACK")) e->opt_stack = atoi(v);           // tuning / A-B experiments
     if (const char* v = getenv("DR_STACK_XCD")) e->opt_stack_xcd = atoi(v);
     if (const char* v = getenv("DR_TAIL")) e->opt_tail = atoi(v);
+    if (const char* v = getenv("DR_BLOCKED")) e->opt_blocked = atoi(v);
     e->n_bins = cfg->n_fft / 2 + 1;
     e->bins_p = round_up(e->n_bins, 64);
     int maxdil = 1;
@@ -1056,10 +1115,11 @@ int dr_commit(dr_engine* e, void* stream) {
         for (int r = 0; r < C; ++r) bb[r] = Bv[r];
         if ((rc = upload(e, pk, &e->in_w)) || (rc = upload(e, bb, &e->in_b))) return rc;
     }
-    for (int l = 0; l < L; ++l) {
-        LayerW& lw = e->layers[l];
-        lw.dil = 1;
-        for (int q = 0; q < l % e->cfg.dilation_bound; ++q) lw.dil *= e->cfg.dilation_base;
+    struct LayerPack { std::vector<float> pconv, pcond, bconv, bconv_u, bconv_z, bcond, pout, bout; };
+    std::vector<LayerPack> packs(L);
+    const double tp0 = now_s();
+    parallel_for(L, [&](int l) {
+        LayerPack& k = packs[l];
         const std::string pre = "residual_layers." + std::to_string(l) + ".";
         const auto& Wd = P(pre + "dilated_conv.weight");
         const auto& Bd = P(pre + "dilated_conv.bias");
@@ -1068,15 +1128,15 @@ int dr_commit(dr_engine* e, void* stream) {
         const auto& Wo = P(pre + "output_projection.weight");
         const auto& Bo = P(pre + "output_projection.bias");
         const int MTc = Cp / 64;   // 2*Cp rows
-        auto pconv = pack_weights(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
+        k.pconv = pack_weights(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
             int mi, c; paired_row(pr, mi, c);
             return (c < C && ch < C) ? Wd[((size_t)(mi * C + c) * C + ch) * K + j] : 0.f;
         });
-        auto pcond = pack_weights(MTc, (NM + 31) / 32, 1, [&](int pr, int ch, int) {
+        k.pcond = pack_weights(MTc, (NM + 31) / 32, 1, [&](int pr, int ch, int) {
             int mi, c; paired_row(pr, mi, c);
             return (c < C && ch < NM) ? Wc[(size_t)(mi * C + c) * NM + ch] : 0.f;
         });
-        std::vector<float> bconv(MTc * 128, 0.f), bconv_u(MTc * 128, 0.f), bconv_z(MTc * 128, 0.f), bcond(MTc * 128, 0.f);
+        k.bconv.assign(MTc * 128, 0.f); k.bconv_u.assign(MTc * 128, 0.f); k.bconv_z.assign(MTc * 128, 0.f); k.bcond.assign(MTc * 128, 0.f);
         for (int pr = 0; pr < MTc * 128; ++pr) {
             int mi, c; paired_row(pr, mi, c);
             if (c >= C) continue;
@@ -1084,41 +1144,39 @@ int dr_commit(dr_engine* e, void* stream) {
             double sw = 0.0;
             for (int m = 0; m < NM; ++m) sw += (double)Wc[(size_t)o * NM + m];
             const float cu = (float)((double)Bc[o] - sw);   // conditioner of spec == -1 (model/diffwave.py:660)
-            bconv[pr] = Bd[o];
-            bconv_u[pr] = Bd[o] + cu;
-            bconv_z[pr] = Bd[o] + Bc[o];                    // conditioner of spec == 0 is its bias
-            bcond[pr] = Bc[o];
+            k.bconv[pr] = Bd[o];
+            k.bconv_u[pr] = Bd[o] + cu;
+            k.bconv_z[pr] = Bd[o] + Bc[o];                  // conditioner of spec == 0 is its bias
+            k.bcond[pr] = Bc[o];
         }
         // 1x1 output projection (2C,C,1): packed rows [0,Cp) residual, [Cp,2Cp) skip
-        auto pout = pack_weights(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
+        k.pout = pack_weights(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
             const int half = pr >= Cp, c = pr - half * Cp;
             return (c < C && ch < C) ? Wo[(size_t)(half * C + c) * C + ch] : 0.f;
         });
-        std::vector<float> bout(MTc * 128, 0.f);
+        k.bout.assign(MTc * 128, 0.f);
         for (int pr = 0; pr < 2 * Cp; ++pr) {
             const int half = pr >= Cp, c = pr - half * Cp;
-            if (c < C) bout[pr] = Bo[half * C + c];
+            if (c < C) k.bout[pr] = Bo[half * C + c];
         }
-        {   // split-bf16 packings of the two hot GEMMs (same row maps, same zero padding)
-            auto pconv3 = pack_weights_s3(MTc, Cp / 32, K, [&](int pr, int ch, int j) {
-                int mi, c; paired_row(pr, mi, c);
-                return (c < C && ch < C) ? Wd[((size_t)(mi * C + c) * C + ch) * K + j] : 0.f;
-            });
-            auto pout3 = pack_weights_s3(MTc, Cp / 32, 1, [&](int pr, int ch, int) {
-                const int half = pr >= Cp, c = pr - half * Cp;
-                return (c < C && ch < C) ? Wo[(size_t)(half * C + c) * C + ch] : 0.f;
-            });
-            if ((rc = upload_bytes(e, pconv3.data(), pconv3.size() * 2, &lw.conv_w3)) ||
-                (rc = upload_bytes(e, pout3.data(), pout3.size() * 2, &lw.out_w3)))
-                return rc;
-        }
-        if ((rc = upload(e, pconv, &lw.conv_w)) || (rc = upload(e, bconv, &lw.conv_b)) ||
-            (rc = upload(e, bconv_u, &lw.conv_b_u)) || (rc = upload(e, bconv_z, &lw.conv_b_z)) ||
-            (rc = upload(e, pcond, &lw.cond_w)) ||
-            (rc = upload(e, bcond, &lw.cond_b)) || (rc = upload(e, pout, &lw.out_w)) ||
-            (rc = upload(e, bout, &lw.out_b)))
+    });
+    e->t_pack_s = now_s() - tp0;
+    const double tu0 = now_s();
+    for (int l = 0; l < L; ++l) {
+        LayerW& lw = e->layers[l];
+        lw.dil = 1;
+        for (int q = 0; q < l % e->cfg.dilation_bound; ++q) lw.dil *= e->cfg.dilation_base;
+        LayerPack& k = packs[l];
+        if ((rc = upload(e, k.pconv, &lw.conv_w)) || (rc = upload(e, k.bconv, &lw.conv_b)) ||
+            (rc = upload(e, k.bconv_u, &lw.conv_b_u)) || (rc = upload(e, k.bconv_z, &lw.conv_b_z)) ||
+            (rc = upload(e, k.pcond, &lw.cond_w)) ||
+            (rc = upload(e, k.bcond, &lw.cond_b)) || (rc = upload(e, k.pout, &lw.out_w)) ||
+            (rc = upload(e, k.bout, &lw.out_b)))
             return rc;
+        k = LayerPack{};
     }
+    e->t_upload_s = now_s() - tu0;
+    e->s3_ready = false;      // the split-bf16 packings (opt-in precision) are built when that mode is first used
     {   // skip projection (C,C,1) and output projection (88,C,1): natural rows
         const auto& Ws = P("skip_projection.weight");
         const auto& Bs = P("skip_projection.bias");
@@ -1206,14 +1264,13 @@ int dr_commit(dr_engine* e, void* stream) {
     if (!e->stack_bar) {     // group counters of the fused residual stack: zero between launches (re-armed in-kernel)
         void* q = nullptr;
         const size_t G4 = (size_t)4 * dr_engine::STACK_GROUPS;
-        const size_t nb = (4 * G4 + 1024 + 16) * sizeof(unsigned);
+        const size_t nb = (3 * G4 + 1024 + 16) * sizeof(unsigned);
         HIPCHK(e, hipMalloc(&q, nb));
         HIPCHK(e, hipMemset(q, 0, nb));
-        e->stack_bar = (unsigned*)q;                                     // [bar][pbar][tail bar][tail pbar][xid][derr]
-        e->stack_pbar = e->stack_bar + G4;
-        e->tail_bar = e->stack_bar + 2 * G4;
-        e->tail_pbar = e->stack_bar + 3 * G4;
-        e->stack_xid = e->stack_bar + 4 * G4;                            // one word per block (<= 1024 CUs)
+        e->stack_bar = (unsigned*)q;                                     // [bar][tail bar][tail pair bar][xid][derr]
+        e->tail_bar = e->stack_bar + G4;
+        e->tail_pbar = e->stack_bar + 2 * G4;
+        e->stack_xid = e->stack_bar + 3 * G4;                            // one word per block (<= 1024 CUs)
         e->stack_derr = e->stack_xid + 1024;
         HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));   // no tag of a launch ever equals 0xFFFFFFFF
         // the "a barrier wait gave up" flag lives in host-visible memory: every later API call sees it without a
@@ -1276,6 +1333,8 @@ int dr_commit(dr_engine* e, void* stream) {
     }
     e->committed = true;
     e->fe_B = e->fe_T = 0;
+    e->t_tables_s = now_s() - tu0 - e->t_upload_s;
+    if (e->prec) return ensure_s3(e);
     return DR_OK;
 }
 
@@ -1461,6 +1520,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         hipStream_t user = st;
         st = e->cap_stream;   // chain() launches on `st`
         Range range("dr_sample: capture + instantiate the chain graph");
+        const double tc0 = now_s();
         HIPCHK(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         e->use_dyn = true;
         rc = chain(e->xwork);
@@ -1472,6 +1532,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         if (ce != hipSuccess) return fail(e, DR_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
         e->graph = gr;
         HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
+        e->t_capture_s = now_s() - tc0;
         e->gkey = key;
     }
     Range range("dr_sample: launch the chain graph");
@@ -1479,6 +1540,7 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     HIPCHK(e, hipMemcpyAsync(e->xwork, d_x, per * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(e, launch_set_dyn(e->d_dyn, seed, first_sample, w, (float)(1.0 + (double)w), st));
     HIPCHK(e, hipGraphLaunch(e->gexec, st));
+    if (e->stack_launches || e->tail_launches) e->unverified = true;      // (the captured chain may hold persistent launches)
     HIPCHK(e, hipMemcpyAsync(d_x, e->xwork, per * sizeof(float), hipMemcpyDeviceToDevice, st));
     return DR_OK;
 }
@@ -1487,7 +1549,10 @@ int dr_finish(dr_engine* e, void* stream) {
     if (!e) return DR_EINVAL;
     DeviceGuard guard(e->cfg.device);
     HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
-    if (!e->stack_err_host || !*e->stack_err_host) return DR_OK;
+    if (!e->stack_err_host || !*e->stack_err_host) {
+        e->unverified = false;
+        return DR_OK;
+    }
     // A group barrier of the fused kernel gave up: something else held CUs while it ran (another engine / stream /
     // process on this device).  Everything computed since the last dr_finish is invalid.  Heal: wait for the
     // device, re-arm, and run this engine on the per-phase kernels from now on (bit-identical results, no
@@ -1496,6 +1561,9 @@ int dr_finish(dr_engine* e, void* stream) {
     int rc = clear_stack_timeout(e);
     if (rc) return rc;
     drop_graph(e);
+    e->unverified = false;
+    if (e->opt_stack) e->healed_from = e->opt_stack;      // (option "fused_rearm" may restore it after clean chains)
+    e->clean_chains = 0;
     e->opt_stack = 0;
     e->stack_fallbacks += 1;
     static std::atomic<bool> warned{false};           // (engines of several host threads may get here together)
@@ -1533,6 +1601,13 @@ int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_nois
     }
     if (rc) return rc;
     rc = dr_finish(e, st);
+    if (rc == DR_OK && e->healed_from && e->opt_rearm > 0 && !e->opt_stack && ++e->clean_chains >= e->opt_rearm) {
+        // option "fused_rearm": the tenant that caused the time-out has had opt_rearm chains to leave - fuse again
+        drop_graph(e);
+        e->opt_stack = e->healed_from;
+        e->healed_from = 0;
+        e->clean_chains = 0;
+    }
     if (rc != DR_ETIMEOUT) return rc;
     if (!may_fuse) return rc;         // cannot happen: no fused launch was issued
     HIPCHK(e, hipMemcpyAsync(d_x, e->xsave, per * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1542,6 +1617,29 @@ int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_nois
     if (rc == DR_OK && recovered) *recovered = 1;
     if (rc == DR_OK) e->err.clear();
     return rc;
+}
+
+int dr_pending_timeout(dr_engine* e, void* stream) {
+    if (!e || !e->stack_err_host) return DR_OK;
+    if (e->unverified) {
+        DeviceGuard guard(e->cfg.device);
+        HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    }
+    if (*e->stack_err_host)
+        return fail(e, DR_ETIMEOUT, "a fused residual-stack launch issued on this engine timed out and has not been checked: the roll is "
+                                    "invalid - call dr_finish (clears the condition, switches to per-phase launches) and recompute, or "
+                                    "use dr_sample_checked");
+    e->unverified = false;
+    return DR_OK;
+}
+
+int dr_cold_times(dr_engine* e, double* out5) {
+    if (!e || !out5) return DR_EINVAL;
+    out5[0] = e->t_pack_s; out5[1] = e->t_upload_s; out5[2] = e->t_tables_s; out5[3] = e->t_capture_s;
+    size_t nodes = 0;
+    if (e->graph && hipGraphGetNodes(e->graph, nullptr, &nodes) != hipSuccess) nodes = 0;
+    out5[4] = (double)nodes;
+    return DR_OK;
 }
 
 int dr_stack_fallbacks(dr_engine* e, int64_t* count) {
@@ -1559,6 +1657,7 @@ int dr_tail_launches(dr_engine* e, int64_t* count) {
 int dr_note_runs(dr_engine* e, const float* d_roll, int B, int T, float threshold, int32_t* d_note_end, void* stream) {
     if (!e || !d_roll || !d_note_end) return fail(e, DR_EINVAL, "null argument");
     if (B <= 0 || T <= 0) return fail(e, DR_EINVAL, "bad shape B=%d T=%d", B, T);
+    if (int rc = dr_pending_timeout(e, stream)) return rc;
     DeviceGuard guard(e->cfg.device);
     HIPCHK(e, launch_note_runs(d_roll, d_note_end, B, T, threshold, (hipStream_t)stream));
     return DR_OK;
@@ -1568,6 +1667,7 @@ int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, siz
                     int64_t* host_counts, void* stream) {
     if (!e || !d_pred || !d_label || !host_counts) return fail(e, DR_EINVAL, "null argument");
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = dr_pending_timeout(e, stream)) return rc;
     DeviceGuard guard(e->cfg.device);
     if (!e->d_counts) {
         void* q = nullptr;
@@ -1589,6 +1689,7 @@ static int noise_mix(dr_engine* e, int mode, const float* a, const float* b, con
     // is then read with dr_last_error(NULL))
     if (!a || !b || !d_t || !d_sac || !d_s1m || !d_out) return fail(e, DR_EINVAL, "null argument");
     if (B <= 0 || n_steps <= 0 || per_sample == 0) return fail(e, DR_EINVAL, "bad shape B=%d n_steps=%d", B, n_steps);
+    if (int rc = dr_pending_timeout(e, stream)) return rc;
     HIPCHK(e, launch_noise_mix(mode, a, b, d_t, d_sac, d_s1m, n_steps, B, (long)per_sample, d_out, (hipStream_t)stream));
     return DR_OK;
 }
@@ -1657,6 +1758,13 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
     };
     if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
     if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
+    if (n == "fused_rearm") { e->opt_rearm = value; return DR_OK; }
+    if (n == "blocked_accumulation") {
+        if (value != 1 && value != 2) return fail(e, DR_EINVAL, "blocked_accumulation is 1 or 2");
+        if (e->opt_blocked != value) drop_graph();
+        e->opt_blocked = value;
+        return DR_OK;
+    }
     if (n == "fused_tail") { if (e->opt_tail != value) drop_graph(); e->opt_tail = value; return DR_OK; }
     if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop_graph(); e->opt_stack_warm = value; return DR_OK; }
     if (n == "stack_fault_test") { if (e->opt_stack_fault != value) drop_graph(); e->opt_stack_fault = value; return DR_OK; }
@@ -1810,6 +1918,7 @@ int dr_set_precision(dr_engine* e, int mode) {
         if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
         e->gkey = GraphKey{};
         e->prec = mode;
+        if (mode) return ensure_s3(e);
     }
     return DR_OK;
 }

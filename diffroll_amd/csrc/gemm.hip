@@ -41,7 +41,7 @@ hipError_t reset_bounds() {
     return reset_bounds_tail();
 }
 
-template <int NI, int KS, int EPI, int PREC, int SK2 = 0>
+template <int NI, int KS, int EPI, int PREC, int SK2 = 0, int FOLDP = (NI == 1 || SK2)>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (SK2) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         ks = rest % a.ksplit;
         nt = rest / a.ksplit;
     }
-    gemm_body<NI, KS, EPI, PREC, 0>(a, smem, mt, nt, ks);
+    gemm_body<NI, KS, EPI, PREC, 0, 0, FOLDP>(a, smem, mt, nt, ks);
 }
 
 template <int NW>
@@ -376,6 +376,25 @@ static hipError_t launch_gemm_half(const GemmArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n) {
+    static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
+    static const long max_blocks_env = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 0;
+    const long max_blocks = max_blocks_env ? max_blocks_env : (prec ? 256 : 2048);
+    const int BN = 64 * NI;
+    const double t_full = (double)kchunks * taps * 16.0 * (2 * NI) * 69.0 / 2400.0;
+    auto cost = [&](int ks) {
+        return (double)((tiles * ks + 255) / 256) * t_full / ks + (ks > 1 ? 4.0 + ks : 0.0);
+    };
+    KSplitPlan p{1, cost(1), cost(1)};
+    for (int ks = 2; ks <= ks_max && ks <= 16; ks *= 2) {
+        if (tiles * ks > max_blocks || nchunks % ks != 0) break;
+        if ((size_t)tiles * ks * 128 * BN > ws_floats || (size_t)tiles * 4 > ws_cnt_n) break;
+        const double c = cost(ks);
+        if (tiles * ks <= 256 || c < 0.97 * p.us) { p.us = std::min(p.us, c); p.ks = ks; }
+    }
+    return p;
+}
+
 template <int NI, int KS, int EPI, int PREC>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int BN = 64 * NI;
@@ -384,39 +403,25 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * tps;
     GemmArgs b = a;
-    // Split-K: launches that cannot fill the chip, and (round 3) launches that fill it unevenly.  The ticket reduction
-    // needs no co-residency (nobody spins), so a launch may be cut into MORE blocks than the chip holds: 10 evaluations
-    // of 125 frames are 160 tiles = one round of full-K blocks on 62 % of the CUs; cut 4x in K they are 640 blocks =
-    // 3 rounds of quarter-length blocks: 136 -> 107 us per conv launch, 2410 -> 1996 us per reverse step.  Cost model in
-    // us per launch (fp32), fitted to 3..8 guided clips of 125 frames (tools/small_batch_ab.py: equal blocks run in
-    // lockstep rounds - 160 / 192 / 224 tiles cut 4x took 107 / 109 / 143 us): rounds x t_full / ks + exchange, with
-    // t_full = a full-K tile (MFMA count x 69 cycles) and the exchange (store, ticket, the last arriver's re-read of
-    // ks partials) ~(4 + ks) us.
+    // Split-K: launches that cannot fill the chip, and launches that fill it unevenly.  The ticket reduction needs no
+    // co-residency (nobody spins), so a launch may be cut into MORE blocks than the chip holds: 10 evaluations of 125
+    // frames are 160 tiles = one round of full-K blocks on 62 % of the CUs; cut 4x in K they are 640 blocks = 3 rounds
+    // of quarter-length blocks: 136 -> 107 us per conv launch.  The decision is plan_ksplit's (shared with the engine).
     b.ksplit = 1;
-    if (a.ws && a.ws_cnt) {
-        static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
-        static const long max_blocks = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : (PREC ? 256 : 2048);
-        const int nchunks = a.kchunks / KS;
-        const long tiles = (long)a.MT * NT;
-        const double t_full = (double)a.kchunks * a.taps * 16.0 * (2 * NI) * 69.0 / 2400.0;
-        auto cost = [&](int ks) {
-            return (double)((tiles * ks + 255) / 256) * t_full / ks + (ks > 1 ? 4.0 + ks : 0.0);
-        };
-        double best = cost(1);
-        for (int ks = 2; ks <= ks_max && ks <= 16; ks *= 2) {
-            if (tiles * ks > max_blocks || nchunks % ks != 0) break;
-            if ((size_t)tiles * ks * 128 * BN > a.ws_floats || (size_t)tiles * 4 > a.ws_cnt_n) break;
-            const double c = cost(ks);
-            // (inside one resident round more slices are taken as before; beyond it a split must win by 3 %)
-            if (tiles * ks <= 256 || c < 0.97 * best) { best = std::min(best, c); b.ksplit = ks; }
-        }
-    }
+    if (a.ws && a.ws_cnt) b.ksplit = plan_ksplit((long)a.MT * NT, a.kchunks / KS, a.kchunks, a.taps, NI, PREC, a.ws_floats, a.ws_cnt_n).ks;
     b.lds_bytes = (int)lds;
     const dim3 grid((unsigned)(a.MT * NT * b.ksplit));
     // weights: MT*128 rows x 32*kchunks*taps floats; activations: NT*BN frames x 32*kchunks floats
     const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = 4.0 * (double)NT * BN * 32.0 * a.kchunks;
     b.xcd_n = pick_xcd_mapping(a.MT, NT, wbytes, xbytes);
     DR_CHECK_EXTENTS(b, EPI, PREC, "gemm_kernel");
+    // the 128-frame gated conv exists with and without blocked accumulation (GemmArgs::fold128)
+    if constexpr (NI == 2 && KS == 1 && EPI == EPI_GATE && PREC == 0) {
+        if (a.fold128) {
+            hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, 0, 0, 1>), grid, dim3(512), lds, s, b);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
     return hipGetLastError();
 }
@@ -453,6 +458,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;
     if ((e = init_tail_kernels()) != hipSuccess) return e;
     if ((e = init_stack_kernels()) != hipSuccess) return e;

@@ -57,7 +57,12 @@ namespace dr {
 //   halves per hand-over, and after the loop the waves of a pair swap the frame half they do not finish through LDS
 //   (wave (r, 0) keeps frames 0-63, wave (r, 1) frames 64-127), add the partner's partial and run the epilogue of their
 //   32 rows x 64 frames.  Output = P0 + P1 with P_h the blocked sum over half h: deterministic, independent of timing.
-template <int NI, int KS, int EPI, int PREC, int COH, int SK2 = 0>
+//   FOLDP: blocked accumulation wanted.  It applies to the gated conv (EPI_GATE: the K = taps x C contraction; every other
+//   GEMM of the path has K <= 1056 and keeps one chain, bit-identical to pw_body) and defaults to on where it is free -
+//   64-frame blocks and half tiles; 128-row x 128-frame blocks pay for the second accumulator set (256 registers, a
+//   few spilled values per phase in the fused kernel: +3-4 % per chain) and take it only on request (engine option
+//   "blocked_accumulation" = 2).
+template <int NI, int KS, int EPI, int PREC, int COH, int SK2 = 0, int FOLDP = (NI == 1 || SK2)>
 DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
     static_assert(!SK2 || (NI == 2 && EPI == EPI_GATE), "half tiles: the gated conv on 128-frame blocks");
     constexpr int BN = 64 * NI;
@@ -205,7 +210,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // (not in the 128-frame split-bf16 flavour: its K loop holds 96 B-fragment registers - 3 pieces x 4 tiles x 2 groups
     // in flight - and has no room for a second accumulator set; that opt-in mode keeps one chain per output there)
-    constexpr bool FOLD = DR_FOLD && !(PREC == 1 && NI == 2);
+    constexpr bool FOLD = DR_FOLD && FOLDP && EPI == EPI_GATE && !(PREC == 1 && NI == 2);
     auto fold = [&]() {
         if constexpr (FOLD) {
 #pragma unroll
@@ -345,6 +350,9 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     static_assert(MI == 1, "one 32-row MFMA tile per consumer wave");
 
     A8 wA = load_a((c0 + ck0) * KS * a.taps), wB;
+#if DR_ABLATE == 1
+    wB = wA;
+#endif
     const int cen = (a.taps - 1) >> 1;
 
     // B fragments of one 8-channel group: NW float4 (one per 32-frame MFMA tile), conflict-free ds_read_b128
@@ -389,8 +397,10 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     auto step = [&](auto ROLE, auto FIRST, int slab, int chunk, int q) {
         constexpr bool kB = decltype(ROLE)::value;
         const float4* Xb = xaddr(chunk, q);
+#if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop (both sets keep the first fragments)
         if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
         else wB = load_a(min(slab + 1, NS - 1));
+#endif
         b1 = rd(Xb, 1);
         mma4(FIRST, kB ? wB.v[0] : wA.v[0], b0);
         b0 = rd(Xb, 2);
@@ -413,7 +423,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // next step's group g right behind the group's last MFMA (one buffer load per group: prefetch distance three
     // groups = 48 MFMAs) - ONE fragment set instead of two, which is what lets the second accumulator set of the
     // blocked accumulation (64 registers at NW = 4) live in the K loop without spilling; no roles, no per-chunk copy.
-    constexpr bool AINP = DR_AINPLACE && (NI == 2);
+    constexpr bool AINP = DR_AINPLACE && (NI == 2) && FOLD;
     auto load_ag = [&](int slab, int g) -> float4 {
         DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 112, slab, NS);
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);
@@ -424,16 +434,26 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         const int nx = min(slab + 1, NS - 1);
         b1 = rd(Xb, 1);
         mma4(FIRST, wA.v[0], b0);
+#if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop
         wA.v[0] = load_ag(nx, 0);
+#endif
         b0 = rd(Xb, 2);
         mma4(F_{}, wA.v[2], b1);
+#if DR_ABLATE != 1
         wA.v[2] = load_ag(nx, 1);
+#endif
         b1 = rd(Xb, 3);
         mma4(F_{}, wA.v[4], b0);
+#if DR_ABLATE != 1
         wA.v[4] = load_ag(nx, 2);
+#endif
         b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
         mma4(F_{}, wA.v[6], b1);
+#if DR_ABLATE != 1
         wA.v[6] = load_ag(nx, 3);
+#else
+        (void)nx;
+#endif
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();

@@ -83,6 +83,7 @@ struct GemmArgs {
     int ksplit;              // set by the launcher
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
     int lds_bytes;           // set by the launcher: dynamic LDS of the launch (read by DR_BOUNDS checker builds only)
+    int fold128;             // EPI_GATE on 128-frame blocks (NI = 2, fp32): 1 = the blocked-accumulation instantiation
     int wt_store;            // fused residual stack only (COH bodies): 1 = the tensors handed to other workgroups are
                              // stored write-through (sc1), 0 = plain stores (every workgroup of the group shares one
                              // XCD's L2, verified at run time)
@@ -106,6 +107,15 @@ hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
 hipError_t launch_pointwise_ksplit(const GemmArgs& a, int NW, hipStream_t s);   // under-filled launches: 32-row tiles, K split over the block's waves
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
+// THE split-K decision of gemm_kernel launches (the launcher takes it; the engine's tile choice prices a launch with it,
+// so the estimate and the launch cannot disagree): for `tiles` output tiles of 128 rows x 64 NI frames, `nchunks` hand-over
+// chunks of K (kchunks / KS), a workspace of ws_floats / ws_cnt_n: the number of K slices and the modelled time.
+// Model (fp32, fitted to 3..8 guided clips of 125 frames, tools/small_batch_ab.py): equal blocks run in lockstep rounds
+// over the 256 CUs - rounds x t_full / ks + exchange, t_full = a full-K tile (MFMA count x 69 cycles at 2.4 GHz), the
+// exchange (store, ticket, the last arriver's ordered re-read) ~(4 + ks) us.  Inside one resident round more slices are
+// always taken; beyond it a split must win by 3 %.
+struct KSplitPlan { int ks; double us; double us_unsplit; };
+KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n);
 
 // ---------------------------------------------------------------------------------------------
 // Fused residual stack: ONE persistent launch runs a range of the 2L phases of the residual layers
@@ -135,6 +145,7 @@ struct StackArgs {
     int rs_off;                               // set by the launcher: LDS byte offset of the resident h / skip tile
     int lds_bytes;                            // set by the launcher: dynamic LDS of the launch (DR_BOUNDS checker builds)
     int fault;                                // test hook: barriers wait for one arrival too many (exercises the spin bound)
+    int fold128;                              // FL = 2: 1 = the instantiation with blocked accumulation in its conv phases
     int warm;                                 // idle waves warm the L2 with the next phase's weights / conditioner tile
     unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)
     unsigned* bar;                            // [groups][4] {arrivals, departures, generation, -}; the first two are zero
@@ -203,6 +214,7 @@ struct TailArgs {
     const float *conv_w, *conv_b, *conv_b2, *cond, *cond2;
     long c_bs;
     int taps, dil;
+    int fold;                                 // blocked accumulation in that conv (gemm_body.h), as the stack launch that follows
     float* g;                                 // its output, P4 [NB][Cp/4][T][4]
     int lds_bytes;                            // set by the launcher
     long long* dbg;                           // optional: block 0 writes s_memtime at the start and after T1, its barrier, T2, its

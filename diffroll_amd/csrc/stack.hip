@@ -13,7 +13,8 @@ DR_BOUNDS_TU(stack)
 // every consumer wave then runs the 128-frame flavour's instruction stream instead of the 64-frame one's.
 // (A 160-frame flavour on the 16x16x4 MFMA existed in rounds 2-3 for 640-frame clips: never faster than the per-phase
 // launches there, 92 spilled registers; removed in round 4.)
-template <int FL>
+// FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavours 1 and 4, on request for flavour 2.
+template <int FL, int FOLDP = 1>
 __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The arguments are read through the kernarg segment pointer (constant address space: scalar loads at the
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
-            if constexpr (HALF) gemm_body<2, 1, EPI_GATE, 0, 1, 1>(a, smem, mt, nt, hf);
-            else gemm_body<FL, 1, EPI_GATE, 0, 1>(a, smem, mt, nt, 0);
+            if constexpr (HALF) gemm_body<2, 1, EPI_GATE, 0, 1, 1, 1>(a, smem, mt, nt, hf);
+            else gemm_body<FL, 1, EPI_GATE, 0, 1, 0, FOLDP>(a, smem, mt, nt, 0);
             // The agent-scope acquire the NEXT phase needs (the 1x1 reads g, written by other workgroups, with plain
             // loads through this CU's L1): one producer wave issues it here, while the consumers still contract the
             // last chunk, instead of everyone waiting ~1.7 us for it behind the barrier.  It is valid anywhere
@@ -266,7 +267,8 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     (void)MT;
     const dim3 grid((unsigned)(gsize * NBp));
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
-    else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2>), grid, dim3(512), lds, st, b);
+    else if (FL == 2 && s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1>), grid, dim3(512), lds, st, b);
+    else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2, 0>), grid, dim3(512), lds, st, b);
     else hipLaunchKernelGGL((stack_kernel<4>), grid, dim3(512), lds, st, b);
     return hipGetLastError();
 }
@@ -285,7 +287,8 @@ size_t stack_lds_bytes(int FL, int taps, int max_dil) {
 hipError_t init_stack_kernels() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 

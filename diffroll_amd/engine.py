@@ -217,6 +217,23 @@ class Engine:
         self._check(self.lib.dr_stack_fallbacks(self.h, C.byref(n)))
         return int(n.value)
 
+    def cold_times(self):
+        """(pack_s, upload_s, tables_s of the last dr_commit; capture + instantiate seconds and kernel-node count of the
+        last captured chain) - include/diffroll_amd.h: dr_cold_times."""
+        out = (C.c_double * 5)()
+        self._check(self.lib.dr_cold_times(self.h, out))
+        return tuple(float(v) for v in out)
+
+    def pending_timeout(self) -> bool:
+        """True when a fused launch timed out and finish() has not been called since (dr_pending_timeout; synchronises the
+        current stream only if fused launches are unverified)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.dr_pending_timeout(self.h, self._stream())
+        if rc == _cabi.DR_ETIMEOUT:
+            return True
+        self._check(rc)
+        return False
+
     @property
     def tail_launches(self) -> int:
         """Tail-kernel launches issued so far (option 'fused_tail')."""

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 7
+#define DR_ABI_VERSION 8
 
 enum {
     DR_OK = 0,
@@ -208,9 +208,17 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  *                phase (fused_stack = 0: bit-identical results, no residency assumption), so the recomputation
  *                cannot time out again; re-enable with dr_set_option when the device is the engine's own again.
  * Call it before a roll produced by dr_forward / dr_step / dr_sample is used (copied to the host, written as MIDI,
- * gathered).  Every other entry point refuses to start (DR_ETIMEOUT) while an unchecked time-out is pending.
+ * gathered).  While an unchecked time-out is pending every entry point that COMPUTES (dr_forward, dr_forward_steps,
+ * dr_step, dr_sample) refuses to start, and every entry point that CONSUMES a roll given an engine handle
+ * (dr_note_runs, dr_frame_counts, dr_q_sample / dr_extract_x0, dr_gather) first does what dr_pending_timeout does -
+ * it synchronises `stream` if fused launches have been issued since the last check - and returns DR_ETIMEOUT instead of
+ * working on an invalid roll.  Only dr_finish (and dr_stack_status) clear the condition.
  */
 int dr_finish(dr_engine* e, void* stream);
+/* The check alone: DR_ETIMEOUT when a fused launch issued on this engine has timed out and dr_finish has not been called
+ * since; DR_OK otherwise.  Synchronises `stream` only when fused launches have been issued since the last check (so that
+ * the flag is final); does not heal, does not clear.  `e` may be NULL (DR_OK). */
+int dr_pending_timeout(dr_engine* e, void* stream);
 /* dr_sample + dr_finish + (on a time-out) the re-run of the chain from the same x_T on the per-phase kernels:
  * returns DR_OK only with the correct roll in d_x.  Synchronous.  *recovered (optional) = 1 when the re-run was
  * needed.  This is what a one-shot caller (sampling.py, predict_step) should use: task/diffusion.py:528-538 returns
@@ -219,6 +227,10 @@ int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_nois
                       float w, uint64_t seed, int first_sample, int use_graph, int32_t* recovered, void* stream);
 /* how many time-outs dr_finish has detected (and healed) on this engine so far */
 int dr_stack_fallbacks(dr_engine* e, int64_t* count);
+/* Start-up costs of this engine, seconds (a one-shot process - sampling.py: load checkpoint, one batch - pays them once):
+ * out5 = {host-side weight packing of the last dr_commit, its uploads, its device-built tables (step embedding),
+ * capture + instantiation of the last chain graph, kernel nodes of that graph}. */
+int dr_cold_times(dr_engine* e, double* out5);
 /* tail-kernel launches issued so far (option "fused_tail"; a captured chain counts once, at capture) */
 int dr_tail_launches(dr_engine* e, int64_t* count);
 
@@ -292,18 +304,26 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
 
 /*
  * Integer options (defaults in brackets).  Changing one drops a captured chain.
+ *   "fused_rearm"      [0] n > 0: after a time-out has switched this engine to per-phase launches, go back to the fused
+ *                          kernels once n chains in a row have finished cleanly (a time-out caused by a transient
+ *                          tenant - a profiler, a second process that has left - then costs n chains at the per-phase
+ *                          pace instead of the rest of the engine's life).  0 = stay on per-phase launches until
+ *                          "fused_stack" is set again.  Seeded results after a recovery can differ from a healthy fused
+ *                          run in the last bits (the per-phase launches split K where the fused kernel does not).
  *   "fused_stack"      [1] the residual layers of an evaluation (model/diffwave.py:678-681: 15 x ResidualBlock.forward,
  *                          :134-151) run as ONE persistent launch whenever samples x frame tiles x M tiles fits the
  *                          chip's CUs in one resident round (the BASELINE configurations 2-4 do); 0 = one launch per
  *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches); 2 = fuse
  *                          also launches that fill less than half the chip (tests).
  *   "fused_tail"       [1] where the evaluation is one fused launch of the 64 / 128-frame flavours, the REST of a reverse
- *                          step is fused too (model/diffwave.py:667-668, :682-686; task/diffusion.py:953-967): under
- *                          classifier-free guidance the first layer's dilated conv - the same contraction for the
- *                          conditional and the unconditional evaluation - becomes phase 0 of the fused launch (done
- *                          once per pair of evaluations), and skip projection, output projection, combine + posterior
- *                          update and the NEXT step's input projection run as one persistent "tail" launch: 2 launches
- *                          per reverse step instead of 6.  0 = separate launches (bit-identical without split-K).
+ *                          step is fused too (model/diffwave.py:667-668, :682-686; task/diffusion.py:953-967): skip
+ *                          projection, output projection, combine + posterior update, the NEXT step's input projection
+ *                          and - under classifier-free guidance - the next step's first-layer dilated conv (the same
+ *                          contraction for the conditional and the unconditional evaluation: done once per pair) run as
+ *                          one persistent "tail" launch, and the following stack launch starts at that layer's 1x1:
+ *                          2 launches per reverse step instead of 6 (the first step of a chain still runs its input
+ *                          projection and first-layer conv as launches of their own).  0 = separate launches
+ *                          (bit-identical without split-K).
  *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
  *                          0 = one weight panel per XCD.  Performance only.
  *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that

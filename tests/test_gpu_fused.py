@@ -36,13 +36,17 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", [1, 2, 4])
+@pytest.mark.parametrize("ni", ["1", "2", "4", "2b"])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
-    pinned to the flavours the fused kernel is built from (the overrides are read once per process)."""
+    pinned to the flavours the fused kernel is built from (the overrides are read once per process).  "2b" = the
+    128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni if ni < 4 else 4), DR_STACK_FL=str(ni))
+    blocked = ni.endswith("b")
+    ni = int(ni.rstrip("b"))
+    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni if ni < 4 else 4), DR_STACK_FL=str(ni),
+               DR_BLOCKED="2" if blocked else "1")
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])

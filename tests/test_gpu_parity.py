@@ -473,9 +473,13 @@ def test_load_from_checkpoint_end_to_end(tmp_path):
 
 def test_cli_drivers_end_to_end(tmp_path):
     """The sampling.py / infer.py command surface (diffroll_amd/cli.py) on the GPU: wav folder in (Custom dataset,
-    utils/custom_dataset.py:55-91), rolls + raw / clean MIDI out, for the three tasks' samplers."""
+    utils/custom_dataset.py:55-91), rolls + raw / clean MIDI out, for the three tasks' samplers - and the written rolls
+    are held to the ORACLE: its chain on the waveforms as the driver ingested them (stereo 22.05 kHz int16 -> mono ->
+    windowed-sinc resampling -> crop / pad), from the same x_T, with the driver's Philox noise replayed on the CPU
+    (oracle/philox.py, pinned by the Random123 known-answer vectors), the same weights (the driver's seeded draw)."""
     import scipy.io.wavfile as wavfile
     from diffroll_amd import cli, midi
+    from oracle import philox
     wav_dir = tmp_path / "audio"
     wav_dir.mkdir()
     rng = np.random.default_rng(0)
@@ -485,21 +489,95 @@ def test_cli_drivers_end_to_end(tmp_path):
         wavfile.write(str(wav_dir / f"clip{i}.wav"), 22050, data)
     common = ["model.args.kernel_size=3", "model.args.residual_channels=64", "model.args.residual_layers=3",
               "task.timesteps=6", "dataloader.batch_size=2"]
+    dev = torch.device("cuda", 0)
+
+    def oracle_rolls(argv, model_seed):
+        """What the driver must have written: per batch, the oracle chain with replayed Philox noise."""
+        cfg = cli.build_config(argv)
+        torch.manual_seed(model_seed)
+        m = cli.make_model(cfg, dev)                                # the same weights the driver drew
+        p = {k: v.detach().cpu().float() for k, v in m.state_dict().items()}
+        a = cfg["model"]["args"]
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_channels=a["residual_channels"], residual_layers=a["residual_layers"], kernel_size=a["kernel_size"],
+                  timesteps=cfg["task"]["timesteps"])
+        sampler = cfg["task"]["sampling"]["type"]
+        g = torch.Generator().manual_seed(int(cfg["seed"]))
+        S, hop = int(cfg["dataset"]["num_samples"]), int(cfg["hop_length"])
+        if cfg["dataset"]["name"] == "Custom":
+            wav = cli.load_wav_folder(cfg["dataset"]["args"])
+            S = min(S, wav.shape[0])
+            wav = wav[:S]
+            T = wav.shape[1] // hop
+        elif cfg["dataset"]["name"] == "Synthetic":
+            wav = 0.1 * torch.randn(S, int(cfg["sequence_length"]), generator=g)
+            T = int(cfg["sequence_length"]) // hop
+        else:
+            wav = torch.zeros(S, int(cfg["sequence_length"]))
+            T = int(cfg["sequence_length"]) // hop
+        x = torch.randn(S, 1, T, 88, generator=g)
+        bs = min(int(cfg["dataloader"]["batch_size"]), S)
+        out = []
+        for bi, lo in enumerate(range(0, S, bs)):
+            hi = min(lo + bs, S)
+            z = philox.chain_noise(int(cfg["seed"]) + bi, 0, hp["timesteps"], hi - lo, T)
+            with torch.no_grad():
+                out.append(R.sample_chain(p, hp, sampler, x[lo:hi], wav[lo:hi], z, w=0.5,
+                                          inpainting_t=cfg["task"]["inpainting_t"] if sampler == "inpainting_ddpm_x0" else None))
+        return out
+
     out = tmp_path / "o_tr"
-    cli.main(["task=transcription", "dataset=Custom", f"dataset.args.audio_path={wav_dir}", "dataset.args.audio_ext=wav",
-              "dataset.args.max_segment_samples=32000", f"output_dir={out}"] + common)
+    argv = ["task=transcription", "dataset=Custom", f"dataset.args.audio_path={wav_dir}", "dataset.args.audio_ext=wav",
+            "dataset.args.max_segment_samples=32000", f"output_dir={out}"] + common
+    torch.manual_seed(71)
+    cli.main(argv)
     rolls = np.load(out / "rolls_batch0.npy")
     assert rolls.shape == (2, 1, 32000 // 512, 88) and np.isfinite(rolls).all()
     assert (out / "rolls_batch1.npy").exists()                   # 3 clips, batch 2 -> a ragged last batch
     assert (out / "raw_midi_0_0.mid").exists() and (out / "clean_midi_e1_0.mid").exists()
-    midi.read_midi_notes(str(out / "raw_midi_0_1.mid"))
+    want = oracle_rolls(argv, 71)
+    for bi, ref in enumerate(want):
+        got = torch.from_numpy(np.load(out / f"rolls_batch{bi}.npy"))
+        assert maxdiff(got, ref) <= ATOL_STEP, (bi, maxdiff(got, ref))
+    # ... and the MIDI files are the notes of those rolls (extract_notes_wo_velocity at the 0.5 threshold)
+    notes = midi.read_midi_notes(str(out / "raw_midi_0_1.mid"))
+    ref_notes = R.extract_notes_wo_velocity(want[0][1, 0].numpy(), want[0][1, 0].numpy())
+    assert len([e for e in notes if (e[1] & 0xF0) == 0x90 and e[3] > 0]) == len(ref_notes[0])
     out = tmp_path / "o_gen"
-    cli.main(["task=generation", "dataset.num_samples=2", "sequence_length=16384", f"output_dir={out}"] + common)
-    assert np.load(out / "rolls_batch0.npy").shape == (2, 1, 32, 88)
+    argv = ["task=generation", "dataset.num_samples=2", "sequence_length=16384", f"output_dir={out}"] + common
+    torch.manual_seed(72)
+    cli.main(argv)
+    got = torch.from_numpy(np.load(out / "rolls_batch0.npy"))
+    assert got.shape == (2, 1, 32, 88)
+    assert maxdiff(got, oracle_rolls(argv, 72)[0]) <= ATOL_STEP
     out = tmp_path / "o_inp"
-    cli.main(["task=inpainting", "task.inpainting_t=[4,12]", "dataset=Synthetic", "dataset.num_samples=2",
-              "sequence_length=16384", f"output_dir={out}"] + common)
-    assert np.isfinite(np.load(out / "rolls_batch0.npy")).all()
+    argv = ["task=inpainting", "task.inpainting_t=[4,12]", "dataset=Synthetic", "dataset.num_samples=2",
+            "sequence_length=16384", f"output_dir={out}"] + common
+    torch.manual_seed(73)
+    cli.main(argv)
+    got = torch.from_numpy(np.load(out / "rolls_batch0.npy"))
+    assert maxdiff(got, oracle_rolls(argv, 73)[0]) <= ATOL_STEP
+
+
+def test_device_philox_noise_equals_the_cpu_replay():
+    """The production noise (on-device Philox4x32-10 keyed by (seed, global sample, step) + Box-Muller,
+    task/diffusion.py:967's role) against its numpy restatement: a seeded chain on the GPU equals the oracle chain fed
+    the replayed z's, also for a shard that starts at a global offset (first_sample)."""
+    from oracle import philox
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=64, residual_layers=3, kernel_size=9, timesteps=8)
+    p = R.synthetic_params(hp, seed=21)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5)
+    g = torch.Generator().manual_seed(2)
+    B, Tn = 3, 50
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    for seed, first in ((0, 0), (0x1234567890ABCDEF, 5)):
+        got, _ = m.sample(x, wav, seed=seed, first_sample=first)
+        z = philox.chain_noise(seed, first, 8, B, Tn)
+        with torch.no_grad():
+            ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, z, w=0.5)
+        assert maxdiff(got.cpu(), ref) <= ATOL_STEP, (seed, first, maxdiff(got.cpu(), ref))
 
 
 def test_odd_channel_padding_at_filled_launches():

@@ -110,10 +110,18 @@ def test_unchecked_timeout_is_loud_at_the_consume_point_and_heals():
     assert time.perf_counter() - t0 < 60.0
     with pytest.raises(EngineTimeout):                        # pending and unchecked: nothing else may start
         eng.step("generation_ddpm_x0", xb.clone(), z[2], 2)
+    # ... and nothing may CONSUME the invalid roll through the C-ABI either: note extraction, frame counts
+    # and the forward-process arithmetic given the engine handle answer DR_ETIMEOUT until dr_finish has been called
+    assert eng.pending_timeout()
+    with pytest.raises(EngineTimeout):
+        eng.note_runs(work, 0.5)
+    with pytest.raises(EngineTimeout):
+        eng.frame_counts(work, work, 0.5)
     with pytest.raises(EngineTimeout, match="recomputed"):
         eng.finish()
     assert eng.fallbacks == 1
     eng.finish()                                              # cleared: a second check is clean
+    assert not eng.pending_timeout()
     work = xb.clone()
     eng.sample("generation_ddpm_x0", work, z, check=False)    # per-phase launches now
     eng.finish()

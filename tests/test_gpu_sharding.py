@@ -124,7 +124,7 @@ def test_one_rank_under_torch_distributed_run():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "1",
-           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-split", "--no-roofline"]
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-split", "--no-roofline", "--no-cold-start"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]

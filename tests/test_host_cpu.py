@@ -555,3 +555,68 @@ def test_output_frames_follow_trim_spec_roll():
     finally:
         type(t).engine = orig
     assert tuple(out.shape) == (0, 1, 641, 88)
+
+
+def test_resampler_against_float64_closed_form_and_scipy_polyphase():
+    """Two independent pins of diffroll_amd.audio.resample (torchaudio 0.11's sinc_interpolation, utils/custom_dataset.py:62;
+    torchaudio itself is absent from this image):
+    (1) the published formula evaluated DIRECTLY in float64, output sample by output sample, from the continuous-time
+        expression y[m] = (base / orig) sum_k x[k] hann(u) sinc(u), u = base (k / orig - m / new) clamped to +-6 - no
+        kernel bank, no strided convolution, no padding bookkeeping shared with the implementation - at the rate pairs
+        the Custom dataset meets (44.1k, 48k, 22.05k, 8k -> 16k): |resample - closed form| <= 1e-6 max|x| (fp32
+        rounding of a <= 80-tap dot product; observed 1.0e-7);
+    (2) scipy.signal.resample_poly (an unrelated polyphase FIR design: Kaiser window) on band-limited signals: the two
+        resamplers agree to 2e-3 in the interior (observed 3.3e-4 .. 6.4e-4) - the bound is the filters' pass-band ripple, not a bug
+        margin: it separates 'resamples correctly' from 'wrong rate / wrong phase / wrong gain' (errors of order 1)."""
+    import math
+    import scipy.signal
+    from diffroll_amd import audio as A
+    rng = np.random.default_rng(3)
+    for orig_f, new_f in ((44100, 16000), (48000, 16000), (22050, 16000), (8000, 16000)):
+        g = math.gcd(orig_f, new_f)
+        orig, new = orig_f // g, new_f // g
+        L = 3 * orig + 17
+        x = rng.standard_normal(L)
+        got = A.resample(torch.from_numpy(x).float(), orig_f, new_f).double().numpy()
+        assert got.shape[0] == math.ceil(new * L / orig)
+        base = min(orig, new) * 0.99
+        k = np.arange(L, dtype=np.float64)
+        m_idx = rng.choice(got.shape[0], size=min(200, got.shape[0]), replace=False)
+        xf = x.astype(np.float32).astype(np.float64)
+        for m in m_idx:
+            u = np.clip(base * (k / orig - m / new), -6.0, 6.0)
+            win = np.cos(u * math.pi / 6 / 2) ** 2
+            sinc = np.where(u == 0, 1.0, np.sin(u * math.pi) / np.where(u == 0, 1.0, u * math.pi))
+            want = (base / orig) * float(np.sum(xf * win * sinc))
+            assert abs(got[m] - want) <= 1e-6 * np.abs(x).max(), (orig_f, m, got[m], want)
+    # (2) scipy's polyphase resampler on band-limited content (tones below 0.35 x the lower Nyquist)
+    for orig_f, new_f in ((44100, 16000), (22050, 16000), (8000, 16000)):
+        n = orig_f // 2
+        t = np.arange(n) / orig_f
+        lim = 0.35 * min(orig_f, new_f) / 2
+        x = sum(a * np.sin(2 * math.pi * f * t + ph) for a, f, ph in
+                ((0.5, 0.11 * lim, 0.3), (0.3, 0.47 * lim, 1.1), (0.2, 0.93 * lim, 2.0)))
+        ours = A.resample(torch.from_numpy(x).float(), orig_f, new_f).numpy()
+        g = math.gcd(orig_f, new_f)
+        ref = scipy.signal.resample_poly(x, new_f // g, orig_f // g)
+        nmin = min(len(ours), len(ref))
+        assert abs(len(ours) - len(ref)) <= 1
+        assert np.abs(ours[200:nmin - 200] - ref[200:nmin - 200]).max() <= 2e-3, (orig_f, np.abs(ours[200:nmin - 200] - ref[200:nmin - 200]).max())
+
+
+def test_philox_replay_matches_the_random123_known_answers():
+    """oracle/philox.py (the CPU restatement of the engine's on-device noise) against the published Philox4x32-10
+    known-answer vectors (Random123 kat_vectors: zero, all-ones and pi-digit counters / keys), and its Box-Muller
+    stream has the moments of N(0, 1) and does not depend on how a batch is split."""
+    from oracle import philox as P
+    u = np.uint32
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = P.philox4x32_10(u(ctr[0]), u(ctr[1]), u(ctr[2]), u(ctr[3]), key[0], key[1])
+        assert tuple(int(v) for v in got) == want
+    z = P.step_noise(9, 0, 8, 125 * 88, 3)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert np.array_equal(z[5:], P.step_noise(9, 5, 3, 125 * 88, 3))           # keyed by the GLOBAL sample index
+    assert not np.array_equal(z, P.step_noise(9, 0, 8, 125 * 88, 4))

@@ -11,11 +11,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 PS="python $R/tools/prof_summary.py"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split > "$OUT/bench_kt.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/bench_kt.log" 2>&1
 echo "kernel trace rc=$?"
-$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split (MI355X, config 2: TWO launches per reverse step - stack_kernel<NI> = fused residual stack, 14 dilated convs + 15 1x1 per launch; tail_kernel = skip / output projection + combine + update + next input projection + next shared first-layer conv; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log - those rows are the front-end, each chain's first input projection / first-layer conv, and the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline > "$OUT/bench_kt1.log" 2>&1
-$PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
+$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, config 2: TWO launches per reverse step - stack_kernel<NI> = fused residual stack, 14 dilated convs + 15 1x1 per launch; tail_kernel = skip / output projection + combine + update + next input projection + next shared first-layer conv; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log - those rows are the front-end, each chain's first input projection / first-layer conv, and the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline > "$OUT/bench_kt1.log" 2>&1
+$PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
 rm -rf "$OUT/kt1"
 for cfg in 1 2 3 4 5 6 7; do
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
@@ -35,10 +35,10 @@ $PS "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_A
 cd "$R"
 mkdir -p profiles_tmp && cp "$OUT"/${RD}_dominant_cfg*_traffic.json profiles/ 2>/dev/null   # so that bench.py finds the stamped record
 for c in 1 2 3 4 5 6 7; do
-  extra="--no-split --no-cpu-baseline"; [ $c = 2 ] && extra=""
+  extra="--no-split --no-cpu-baseline --no-cold-start"; [ $c = 2 ] && extra=""
   timeout 900 python bench.py --config $c $extra > "$OUT/${RD}_bench_cfg$c.json" 2> "$OUT/bench_cfg$c.err"; echo "bench cfg$c rc=$?"
 done
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
 rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
 timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
 timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"

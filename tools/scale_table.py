@@ -4,7 +4,13 @@ BASELINE configurations, with per-rank chain times (straggler visibility), the f
 weak-scaling efficiency against N = 1 - the reference reaches N GPUs with one flag (config/sampling.yaml:20-21,
 sampling.py:70), and so does `bench.py --gpus N` (it starts its own ranks).
 
-    python tools/scale_table.py [--gpus 1,2,4,8] [--configs 2,3,4,5] [--steps 3] [--warmup 1] [--out table.json]
+    python tools/scale_table.py [--gpus 1,2,4,8] [--configs 2,3,4,5] [--steps 3] [--warmup 1] [--out table.json] [--scale-json SCALE.json]
+
+--scale-json writes a SCALE-shaped record: per configuration and per N the whole-job value, per-rank min / max chain
+time, the gather on its own, ranks_seen, backend, the RCCL version (also as RCCL prints it: NCCL_DEBUG=VERSION is set for
+every run and its banner line is kept) and the weak-scaling efficiency against N = 1.  The exit code is non-zero when any
+cell that ran saw a number of ranks different from the N it was asked for - a run that silently fell back to fewer
+processes must not pass for a scaling point.
 
 Each cell is one `python bench.py --gpus N --config C --no-split --no-cpu-baseline --no-roofline` run; a world size
 the node cannot serve (fewer visible devices) is reported as such and skipped, so the same command works on a 1-GPU
@@ -23,9 +29,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_cell(n, cfg, steps, warmup, timeout):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", str(cfg), "--steps", str(steps),
-           "--warmup", str(warmup), "--no-split", "--no-cpu-baseline", "--no-roofline"]
+           "--warmup", str(warmup), "--no-split", "--no-cpu-baseline", "--no-roofline", "--no-cold-start"]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["NCCL_DEBUG"] = env.get("NCCL_DEBUG", "VERSION")           # RCCL prints its own version banner once per job
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):      # always a fresh launch, never "under a launcher"
         env.pop(k, None)
     t0 = time.perf_counter()
@@ -40,7 +47,37 @@ def run_cell(n, cfg, steps, warmup, timeout):
         return {"error": tail[0][:200], "rc": r.returncode}
     j = json.loads(line)
     j["_wall_s"] = round(wall, 1)
+    banner = [ln.strip() for ln in (r.stdout + "\n" + r.stderr).splitlines() if "RCCL version" in ln or "NCCL version" in ln]
+    j["_rccl_banner"] = banner[0][:160] if banner else None
     return j
+
+
+def scale_record(table, gpus, configs):
+    """The SCALE-shaped record (what the driver writes per round for one configuration, here for all of them)."""
+    rec = {"tool": "tools/scale_table.py", "gpus_requested": gpus, "configs": {}, "ok": True, "problems": []}
+    for c in configs:
+        rows, base = [], None
+        for n in gpus:
+            j = table.get(f"config{c}/gpus{n}", {})
+            if "error" in j:
+                rows.append({"n_gpus": n, "skipped": True, "reason": j["error"]})
+                continue
+            d = j.get("dist", {})
+            seen = d.get("ranks_seen")
+            if seen != n or j.get("n_gpus") != n:
+                rec["ok"] = False
+                rec["problems"].append(f"config {c}: asked for {n} ranks, the job saw {seen} (n_gpus {j.get('n_gpus')})")
+            if base is None and n == 1:
+                base = j["value"]
+            pr = j.get("per_rank_ms_per_step", {})
+            rows.append({"n_gpus": n, "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],
+                         "per_rank_ms_min": pr.get("min"), "per_rank_ms_max": pr.get("max"), "gather_us": j.get("gather_us"),
+                         "ranks_seen": seen, "backend": d.get("backend"), "rccl_version": d.get("rccl_version"),
+                         "rccl_banner": j.get("_rccl_banner"), "launcher": d.get("launcher"), "scaling": j.get("scaling"),
+                         "efficiency_vs_n1": (j["value"] / (n * base)) if base else None, "wall_s": j["_wall_s"],
+                         "workload": j.get("config", {}).get("workload")})
+        rec["configs"][str(c)] = rows
+    return rec
 
 
 def main():
@@ -51,6 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--timeout", type=int, default=1200)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--scale-json", default=None)
     args = ap.parse_args()
     gpus = [int(v) for v in args.gpus.split(",")]
     configs = [int(v) for v in args.configs.split(",")]
@@ -75,7 +113,14 @@ def main():
     if args.out:
         with open(args.out, "w") as f:
             json.dump(table, f, indent=1)
+    rec = scale_record(table, gpus, configs)
+    if args.scale_json:
+        with open(args.scale_json, "w") as f:
+            json.dump(rec, f, indent=1)
+    for p in rec["problems"]:
+        print("PROBLEM:", p)
+    return 0 if rec["ok"] else 1
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -73,6 +73,9 @@ def main():
         step()
         flag, ticks = eng.stack_status(128)
         print(f"xcd={xcd}: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
+        cs = [t for t in ticks[66:80] if t]            # chunk-start marks of block 0's last conv phase (first 14 chunks)
+        if len(cs) > 1:
+            print(f"xcd={xcd}: last conv phase, block 0: first chunk opens at {cs[0]}, chunk durations {[b - a for a, b in zip(cs[:-1], cs[1:])]}")
         wall = ticks[121] - ticks[120]                 # constant 100 MHz counter over the same span as the phase marks
         ticks = ticks[:2 * hp["residual_layers"] + 2]
         nz = [t for t in ticks[:-1] if t]
