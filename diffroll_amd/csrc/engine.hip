@@ -397,7 +397,7 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
         // "32:4": half tiles (64 packed rows x 128 frames, in-block K split) for the fp32 gated conv, else 128-frame tiles
         if (ff == 0 && fn == 4) {
             const bool ok = prec == 0 && epi == EPI_GATE && taps > 1 && allow16 && (MT % 1 == 0) &&
-                            2 * gemm_lds_bytes(2, 1, taps, dil, 0, EPI_GATE) <= 160 * 1024;
+                            gemm_lds_bytes(2, 2, taps, dil, 0, EPI_GATE) <= 160 * 1024;
             if (ok) return Tile{0, 4};
             if (feasible(cands[3])) return Tile{0, 1};      // (the shared first-layer conv: 64-frame blocks accumulate blocked, as half tiles do)
         }

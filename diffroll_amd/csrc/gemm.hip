@@ -359,11 +359,11 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
     return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * 64 * NI * 16 : 0);
 }
 
-// half tiles (gemm_body, SK2 = 1): the gated conv as 2 MT x NT blocks of 64 packed rows x 128 frames
+// half tiles (gemm_body, SK2 = 1): the gated conv as 2 MT x NT blocks of 64 packed rows x 128 frames, 64-channel hand-overs
 template <int PREC>
 static hipError_t launch_gemm_half(const GemmArgs& a, hipStream_t s) {
     if ((a.kchunks & 1) || a.dual > 0) return hipErrorInvalidValue;
-    const size_t lds = 2 * gemm_lds_bytes(2, 1, a.taps, a.dil, PREC, EPI_GATE);       // one X tile per K half
+    const size_t lds = gemm_lds_bytes(2, 2, a.taps, a.dil, PREC, EPI_GATE);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int NT = a.NB * ((a.T + 127) / 128);
     GemmArgs b = a;
@@ -372,7 +372,7 @@ static hipError_t launch_gemm_half(const GemmArgs& a, hipStream_t s) {
     const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = 4.0 * (double)NT * 128 * 32.0 * a.kchunks;
     b.xcd_n = pick_xcd_mapping(2 * a.MT, NT, wbytes, xbytes);
     DR_CHECK_EXTENTS(b, EPI_GATE, PREC, "gemm_kernel (half tiles)");
-    hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, PREC, 1>), dim3((unsigned)(2 * a.MT * NT)), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((gemm_kernel<2, 2, EPI_GATE, PREC, 1>), dim3((unsigned)(2 * a.MT * NT)), dim3(512), lds, s, b);
     return hipGetLastError();
 }
 
@@ -457,7 +457,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 2, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;
     if ((e = init_tail_kernels()) != hipSuccess) return e;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
-            if constexpr (HALF) gemm_body<2, 1, EPI_GATE, 0, 1, 1, 1>(a, smem, mt, nt, hf);
+            if constexpr (HALF) gemm_body<2, 2, EPI_GATE, 0, 1, 1, 1>(a, smem, mt, nt, hf);
             else gemm_body<FL, 1, EPI_GATE, 0, 1, 0, FOLDP>(a, smem, mt, nt, 0);
             // The agent-scope acquire the NEXT phase needs (the 1x1 reads g, written by other workgroups, with plain
             // loads through this CU's L1): one producer wave issues it here, while the consumers still contract the
