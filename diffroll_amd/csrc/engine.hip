@@ -394,13 +394,6 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
     };
     if (forced && strlen(forced) >= 4) {
         const int ff = forced[0] == '1' ? 1 : 0, fn = atoi(forced + 3);
-        // "32:4": half tiles (64 packed rows x 128 frames, in-block K split) for the fp32 gated conv, else 128-frame tiles
-        if (ff == 0 && fn == 4) {
-            const bool ok = prec == 0 && epi == EPI_GATE && taps > 1 && allow16 && (MT % 1 == 0) &&
-                            gemm_lds_bytes(2, 2, taps, dil, 0, EPI_GATE) <= 160 * 1024;
-            if (ok) return Tile{0, 4};
-            if (feasible(cands[3])) return Tile{0, 1};      // (the shared first-layer conv: 64-frame blocks accumulate blocked, as half tiles do)
-        }
         for (const Cand& c : cands)
             if (c.flavor == ff && c.n == fn && feasible(c)) return Tile{ff, fn};
     }
@@ -579,8 +572,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
-        // Flavours 1 / 2 (128 packed rows x 64 / 128 frames per block) and 4 (half tiles: 64 rows x 128 frames, K split
-        // over the block's wave pairs) are chosen automatically; DR_STACK_FL=n pins one (tests / measurements).
+        // Flavours 1 / 2 (128 packed rows x 64 / 128 frames per block) are chosen automatically; DR_STACK_FL=n pins one
+        // (tests / measurements).
         static const int fl_force = getenv("DR_STACK_FL") ? atoi(getenv("DR_STACK_FL")) : 0;
         // A launch must be ONE resident round (groups spin on each other), so an evaluation with more samples than
         // fit is launched in balanced CHUNKS of samples, one fused launch after the other (samples are independent).
@@ -602,8 +595,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             return best;
         };
         double best = 1e30;
-        static const double half_pen = getenv("DR_STACK_HALF_PEN") ? atof(getenv("DR_STACK_HALF_PEN")) : 1.03;
-        for (int fl : {1, 2, 4}) {
+        for (int fl : {1, 2}) {
             if (fl_force && fl != fl_force) continue;
             const int bn = stack_tile_frames(fl);
             const long gsize = stack_group_blocks(fl, Cp, T);                           // blocks per sample
@@ -613,9 +605,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
-            // (a half tile is half the rows of the others' blocks: it costs like 64 frames of a 128-row block, at the
-            // 128-frame flavour's pace plus the in-block exchange)
-            const double cost = (1.0 - 0.025 / chunks) * chunks * (fl == 4 ? 64 * half_pen : bn * (fl == 1 ? 1.0 / 0.93 : 1.0));
+            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : 1.0);
             // (a single launch that leaves more than a fifth of the CUs idle is better served by the per-phase kernels'
             // split-K, which this cost model does not see: they cut the same work into many short blocks that balance
             // over all CUs - 8 evaluations x 125 frames (half the chip): 1365 vs 2422 us per step, 10 / 12 evaluations
@@ -778,9 +768,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (use_tail) {
         // the rest of the step in one launch: skip projection, output projection, combine + update, next input projection
         TailArgs ta{};
-        // (grouping of the tail launch: half tiles have 2 MT blocks per 128-frame tile - the tail takes the 64-frame
-        // grouping, MT blocks per 64-frame tile, which never needs more blocks than the stack launch had)
-        ta.NB = NB; ta.T = T; ta.Cp = Cp; ta.BN = stack_ni == 4 ? 64 : stack_tile_frames(stack_ni);
+        ta.NB = NB; ta.T = T; ta.Cp = Cp; ta.BN = stack_tile_frames(stack_ni);
         ta.dual = (bmod > 0 && NB == 2 * bmod) ? bmod : 0;
         ta.u_B = tail->u_B;
         ta.xcd_n = e->opt_stack_xcd; ta.fault = e->opt_stack_fault;

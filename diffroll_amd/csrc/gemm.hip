@@ -41,24 +41,9 @@ hipError_t reset_bounds() {
     return reset_bounds_tail();
 }
 
-template <int NI, int KS, int EPI, int PREC, int SK2 = 0, int FOLDP = (NI == 1 || SK2)>
+template <int NI, int KS, int EPI, int PREC, int FOLDP = (NI == 1)>
 __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (SK2) {
-        // half tiles (gemm_body, SK2): 2 MT blocks of 64 packed rows per frame tile, K split over the block's wave pairs
-        const int MH = 2 * a.MT;
-        int h, nt;
-        if (a.xcd_n) {
-            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-            h = idx % MH;
-            nt = (idx / MH) * 8 + xcd;
-        } else {
-            h = blockIdx.x % MH;
-            nt = blockIdx.x / MH;
-        }
-        gemm_body<NI, KS, EPI, PREC, 0, 1>(a, smem, h >> 1, nt, h & 1);
-        return;
-    }
     // blockIdx.x % MT = M tile: with MT == 8 each XCD (block b runs on XCD b % 8) streams exactly
     // one 128-row weight panel, which then stays resident in that XCD's private L2.
     // xcd_n != 0 (X-heavy 1x1 GEMMs: small weights, big activations): the 8 M tiles of one frame tile
@@ -79,7 +64,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmArgs a) {
         ks = rest % a.ksplit;
         nt = rest / a.ksplit;
     }
-    gemm_body<NI, KS, EPI, PREC, 0, 0, FOLDP>(a, smem, mt, nt, ks);
+    gemm_body<NI, KS, EPI, PREC, 0, FOLDP>(a, smem, mt, nt, ks);
 }
 
 template <int NW>
@@ -359,23 +344,6 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
     return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * 64 * NI * 16 : 0);
 }
 
-// half tiles (gemm_body, SK2 = 1): the gated conv as 2 MT x NT blocks of 64 packed rows x 128 frames, 64-channel hand-overs
-template <int PREC>
-static hipError_t launch_gemm_half(const GemmArgs& a, hipStream_t s) {
-    if ((a.kchunks & 1) || a.dual > 0) return hipErrorInvalidValue;
-    const size_t lds = gemm_lds_bytes(2, 2, a.taps, a.dil, PREC, EPI_GATE);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int NT = a.NB * ((a.T + 127) / 128);
-    GemmArgs b = a;
-    b.ksplit = 1;
-    b.lds_bytes = (int)lds;
-    const double wbytes = 4.0 * 128.0 * a.MT * 32.0 * a.kchunks * a.taps, xbytes = 4.0 * (double)NT * 128 * 32.0 * a.kchunks;
-    b.xcd_n = pick_xcd_mapping(2 * a.MT, NT, wbytes, xbytes);
-    DR_CHECK_EXTENTS(b, EPI_GATE, PREC, "gemm_kernel (half tiles)");
-    hipLaunchKernelGGL((gemm_kernel<2, 2, EPI_GATE, PREC, 1>), dim3((unsigned)(2 * a.MT * NT)), dim3(512), lds, s, b);
-    return hipGetLastError();
-}
-
 KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n) {
     static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
     static const long max_blocks_env = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 0;
@@ -418,7 +386,7 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     // the 128-frame gated conv exists with and without blocked accumulation (GemmArgs::fold128)
     if constexpr (NI == 2 && KS == 1 && EPI == EPI_GATE && PREC == 0) {
         if (a.fold128) {
-            hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, 0, 0, 1>), grid, dim3(512), lds, s, b);
+            hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, 0, 1>), grid, dim3(512), lds, s, b);
             return hipGetLastError();
         }
     }
@@ -457,8 +425,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<2, 1, EPI_GATE, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 2, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;
     if ((e = init_tail_kernels()) != hipSuccess) return e;
     if ((e = init_stack_kernels()) != hipSuccess) return e;
@@ -481,10 +448,6 @@ static hipError_t launch_gemm_ni(const GemmArgs& a, int epi, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec) {
     if (a.kchunks < 1) return hipErrorInvalidValue;   // the X tile width is only bounded by LDS (checked per launch)
-    if (NI == 4) {                                    // half tiles: 64 packed rows x 128 frames, the gated conv in fp32
-        if (epi != EPI_GATE || prec != 0) return hipErrorInvalidValue;
-        return launch_gemm_half<0>(a, s);
-    }
     if (prec == 1) {   // split-bf16 input: only the two hot kernels exist in this precision
         if (epi == EPI_GATE) return NI == 1 ? launch_gemm_t<1, 1, EPI_GATE, 1>(a, s) : launch_gemm_t<2, 1, EPI_GATE, 1>(a, s);
         if (epi == EPI_RES_SKIP && a.taps == 1)

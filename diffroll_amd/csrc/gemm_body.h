@@ -48,30 +48,15 @@ namespace dr {
 //   The fold (NW x 16 adds per chunk) sits behind the hand-over barrier, under the latency of the chunk's first
 //   fragment reads; the chunk's first MFMAs take a zero C operand, so nothing is cleared.
 //
-//   SK2 = 1 ("half tiles": 64 packed rows x 128 frames per block, NI = 2, KS = 2): for launches whose outputs per CU
-//   are half a 128 x 128 tile (16 evaluations x 125 frames: BASELINE config 3's per-GPU shape) - instead of 128 rows x
-//   64 frames with two MFMAs per weight fragment, the block takes rows [64 ks, 64 ks + 64) of its M tile (`ks` = the row
-//   half here) and its four consumer waves split K IN-BLOCK BY TAPS: both waves of a pair (w >> 1) contract the 32 rows
-//   of wave tile (w & 1) over all 128 frames - exactly the 128-frame flavour's instruction stream (four MFMAs per weight
-//   fragment, 64 per K step) - and of every 64-channel hand-over (two 32-channel sub-chunks, ONE X tile shared by all
-//   four waves: the same staging traffic per MFMA as the 128-frame flavour) pair 0 takes taps [0, ceil(k/2)) of
-//   sub-chunk 0 and taps [0, floor(k/2)) of sub-chunk 1, pair 1 the other taps: k steps each, balanced for odd k.
-//   (Splitting K by CHANNELS instead - round 4's first version - needs one X tile per half per hand-over: the doubled
-//   LDS-DMA traffic cost 1.7 k cycles per chunk, profiles/r04_conv_flavour_ab.txt.)  After the loop the waves of a pair
-//   swap the frame half they do not finish through LDS (wave (r, 0) keeps frames 0-63, wave (r, 1) frames 64-127), add
-//   the partner's partial and run the epilogue of their 32 rows x 64 frames.  Output = P0 + P1 with P_h the blocked sum
-//   (one chain per hand-over: k x 32 terms) over pair h's share of K: deterministic, independent of timing.
 //   FOLDP: blocked accumulation wanted.  It applies to the gated conv (EPI_GATE: the K = taps x C contraction; every other
 //   GEMM of the path has K <= 1056 and keeps one chain, bit-identical to pw_body) and defaults to on where it is free -
-//   64-frame blocks and half tiles; 128-row x 128-frame blocks pay for the second accumulator set (256 registers, a
-//   few spilled values per phase in the fused kernel: +3-4 % per chain) and take it only on request (engine option
-//   "blocked_accumulation" = 2).
-template <int NI, int KS, int EPI, int PREC, int COH, int SK2 = 0, int FOLDP = (NI == 1 || SK2)>
+//   64-frame blocks (+0.9 % per config-3 chain); 128-row x 128-frame blocks pay for the second accumulator set (256
+//   registers, a few spilled values per phase in the fused kernel: +4 % per config-2 chain) and take it only on request
+//   (engine option "blocked_accumulation" = 2).  profiles/r04_conv_flavour_ab.txt.
+template <int NI, int KS, int EPI, int PREC, int COH, int FOLDP = (NI == 1)>
 DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
-    static_assert(!SK2 || (NI == 2 && KS == 2 && EPI == EPI_GATE && PREC == 0), "half tiles: the fp32 gated conv on 128-frame blocks, 64-channel hand-overs");
     constexpr int BN = 64 * NI;
     constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
-    constexpr int NH = 1;                         // X tiles staged per hand-over
     // Consumer wave arrangement: 4 (M) x 1 (N) - every wave owns 32 distinct rows x all 64*NI frames of the
     // block, so no two waves issue the same A-fragment loads (a CU's vector-memory path is the stressed
     // resource: with 2 x 2 the two N-waves fetched identical fragments); the X tile is shared through LDS.
@@ -92,13 +77,13 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 
     const int halo = ((a.taps - 1) >> 1) * a.dil;
     const int FW = BN + 2 * halo;
-    float4* Xs = reinterpret_cast<float4*>(smem);   // [2 buffers][NH][XP][FW]
+    float4* Xs = reinterpret_cast<float4*>(smem);   // [2 buffers][XP][FW]
     // EPI_RES_SKIP: the tile of h (residual rows) / skip (skip rows) this block read-modify-writes,
     // [32 planes][BN frames] float4, DMA'd by the producers at kernel start and read by the epilogue.
     // (Holding it in 64 prefetch VGPRs instead cost the compiler the B-fragment software pipelining.)
-    float4* Rs = Xs + 2 * NH * XP * FW;
+    float4* Rs = Xs + 2 * XP * FW;
 #ifdef DR_BOUNDS
-    const unsigned xs0 = lds_off(Xs), xs1 = xs0 + 2u * NH * XP * FW * 16u, rs1 = xs1 + (EPI == EPI_RES_SKIP ? 32u * BN * 16u : 0u);
+    const unsigned xs0 = lds_off(Xs), xs1 = xs0 + 2u * XP * FW * 16u, rs1 = xs1 + (EPI == EPI_RES_SKIP ? 32u * BN * 16u : 0u);
     if (tid == 0 && !COH) DR_CHECK(rs1 <= (unsigned)a.lds_bytes, 100, rs1, a.lds_bytes);      // the regions fit the launch's LDS
 #endif
 
@@ -107,9 +92,8 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     const int b = nt / tps;
     const int t0 = (nt % tps) * BN;
     const int NS = a.kchunks * a.taps;              // K steps (32 channels x 1 tap each)
-    // chunks (hand-overs) of this block: [c0, c1) of the split-K slice ks; with SK2 all of them (ks is the row half)
-    const int cps = SK2 ? a.kchunks / KS : a.kchunks / KS / a.ksplit;
-    const int c0 = SK2 ? 0 : ks * cps, c1 = c0 + cps;
+    const int cps = a.kchunks / KS / a.ksplit;      // chunks (hand-overs) of this block: [c0, c1)
+    const int c0 = ks * cps, c1 = c0 + cps;
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers (LDS-DMA)
@@ -126,13 +110,11 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         const int last_plane = a.x_planes - 1;
         const unsigned recs = ((unsigned)(a.T - 1) * (unsigned)a.x_fs + 4u) * 4u;   // bytes of one plane row
         const int wl = (FW + 63) >> 6;                  // wave-loads per plane row
-        const int total = NH * XP * wl;
+        const int total = XP * wl;
         typedef __attribute__((address_space(3))) void* lds_ptr;
-        auto issue = [&](int hand) {
+        auto issue = [&](int chunk) {
             for (int i = pw; i < total; i += 4) {
-                const int kh = SK2 ? i / (XP * wl) : 0, i1 = i - kh * (XP * wl);
-                const int pl = i1 / wl, seg = i1 - pl * wl;
-                const int chunk = hand + kh * cps;        // (SK2: the tile of K half kh)
+                const int pl = i / wl, seg = i - pl * wl;
                 const int f = seg * 64 + lane;
                 // planes beyond Cin (K padding) re-read the last valid plane: finite data x zero weights
                 const float* src;
@@ -145,7 +127,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                 }
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, recs, 0x00020000);
                 const int voff = (t0 - halo + f) * (int)a.x_fs * 4;   // negative / past the end => reads 0
-                float4* dst = Xs + ((((hand - c0) & 1) * NH + kh) * XP + pl) * FW + seg * 64;
+                float4* dst = Xs + (((chunk - c0) & 1) * XP + pl) * FW + seg * 64;
                 if (f < FW) DR_CHECK_LDS(dst + lane, xs0, xs1, 101);
                 if (f < FW) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voff, 0, 0, COH ? 16 : 0);
             }
@@ -182,31 +164,11 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             if (chunk + 1 < c1) issue(chunk + 1);
 #endif
         }
-        if constexpr (SK2) {       // the consumers' two exchange barriers (below)
-            __syncthreads();
-            __syncthreads();
-        }
         return;
     }
 
     // ---------------------------------------------------------------------- consumers
-    // SK2: wave tile (w & 1) of row half ks, tap share kh = w >> 1 of every hand-over
-    const int wr = SK2 ? ks * 2 + (wave & 1) : wave / WNC, wc = SK2 ? 0 : wave % WNC;
-    const int kh = SK2 ? (wave >> 1) : 0;
-    constexpr int ck0 = 0;
-    // step q of a hand-over -> (32-channel sub-chunk, tap).  Plain: tap-major, sub-chunk minor (memory order of the
-    // slabs when KS = 1).  SK2: this wave's k steps - pair 0: sub-chunk 0 taps [0, s0), sub-chunk 1 taps [0, s1);
-    // pair 1: sub-chunk 0 taps [s0, k), sub-chunk 1 taps [s1, k), with s0 = ceil(k / 2), s1 = floor(k / 2).
-    const int sk_s0 = (a.taps + 1) >> 1, sk_s1 = a.taps >> 1;
-    const int sk_n0 = kh ? a.taps - sk_s0 : sk_s0;              // steps this wave spends in sub-chunk 0
-    auto map_q = [&](int q, int& sub, int& j) {
-        if constexpr (SK2) {
-            if (q < sk_n0) { sub = 0; j = (kh ? sk_s0 : 0) + q; }
-            else { sub = 1; j = (kh ? sk_s1 : 0) + (q - sk_n0); }
-        } else {
-            j = q / KS; sub = q - j * KS;
-        }
-    };
+    const int wr = wave / WNC, wc = wave % WNC;
     const int r = lane & 31, hi = lane >> 5;
     // this lane's A fragments inside a slab: fp32 [g][hi][row][4] (16 KiB); S3 [g16][piece][kq][row][8 bf16] (24 KiB)
 
@@ -262,7 +224,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             }
             return o;
         };
-        A12 wA = load_a3((c0 + ck0) * KS * a.taps), wB;
+        A12 wA = load_a3(c0 * KS * a.taps), wB;
 #if DR_ABLATE == 1
         wB = wA;
 #endif
@@ -332,7 +294,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         for (int chunk = c0; chunk < c1; ++chunk) {
             auto at = [&](auto R, auto FIRST, int q) {
                 const int j = q / KS, sub = q - j * KS;
-                step(R, FIRST, ((chunk + ck0) * KS + sub) * a.taps + j, chunk, q);
+                step(R, FIRST, (chunk * KS + sub) * a.taps + j, chunk, q);
             };
             __syncthreads();
             b0 = rd3(xaddr(chunk, 0), 0);
@@ -366,13 +328,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     };
     static_assert(MI == 1, "one 32-row MFMA tile per consumer wave");
 
-    int first_slab = (c0 + ck0) * KS * a.taps;
-    if constexpr (SK2) {
-        int j, sub;
-        map_q(0, sub, j);
-        first_slab = sub * a.taps + j;             // this wave's first step of hand-over 0
-    }
-    A8 wA = load_a(first_slab), wB;
+    A8 wA = load_a(c0 * KS * a.taps), wB;
 #if DR_ABLATE == 1
     wB = wA;
 #endif
@@ -382,8 +338,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     struct BF { float4 v[NW]; };
     BF b0, b1;                                   // groups 0/2 and 1/3 of the step in flight
     auto xaddr = [&](int chunk, int q) -> const float4* {     // X tile address of step q of a chunk
-        int j, sub;
-        map_q(q, sub, j);
+        const int j = q / KS, sub = q - j * KS;
         return Xs + (((chunk - c0) & 1) * XP + sub * 8 + hi) * FW + halo + (j - cen) * a.dil + wc * WFR + r;
     };
     auto rd = [&](const float4* Xb, int g) -> BF {
@@ -417,16 +372,13 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // ROLE (compile time) selects which of the two A-fragment register sets is consumed; the other receives
     // the next step's fragments (prefetch distance one step), requested at the top of the step.  Roles
     // alternate statically: no per-step register copies.
-    const int per_chunk = SK2 ? a.taps : a.taps * KS;
-    auto step = [&](auto ROLE, auto FIRST, int slab, int nslab, int chunk, int q) {
+    const int per_chunk = a.taps * KS;
+    auto step = [&](auto ROLE, auto FIRST, int slab, int chunk, int q) {
         constexpr bool kB = decltype(ROLE)::value;
         const float4* Xb = xaddr(chunk, q);
-        const int nxs = SK2 ? min(nslab, NS - 1) : min(slab + 1, NS - 1);    // (SK2: this wave's slabs are not consecutive)
 #if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop (both sets keep the first fragments)
-        if constexpr (kB) wA = load_a(nxs);
-        else wB = load_a(nxs);
-#else
-        (void)nxs;
+        if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
+        else wB = load_a(min(slab + 1, NS - 1));
 #endif
         b1 = rd(Xb, 1);
         mma4(FIRST, kB ? wB.v[0] : wA.v[0], b0);
@@ -456,9 +408,9 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);
         return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
     };
-    auto stepi = [&](auto FIRST, int slab, int nslab, int chunk, int q) {
+    auto stepi = [&](auto FIRST, int slab, int chunk, int q) {
         const float4* Xb = xaddr(chunk, q);
-        const int nx = SK2 ? min(nslab, NS - 1) : min(slab + 1, NS - 1);     // (SK2: this wave's slabs are not consecutive)
+        const int nx = min(slab + 1, NS - 1);
         b1 = rd(Xb, 1);
         mma4(FIRST, wA.v[0], b0);
 #if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop
@@ -491,26 +443,23 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // tap-major, sub-chunk minor.  Roles alternate A,B,A,...; a chunk always starts in role A (one
     // register copy per chunk when per_chunk is odd).
     for (int chunk = c0; chunk < c1; ++chunk) {
-        auto slab_at = [&](int ch, int q) {
-            int j, sub;
-            map_q(q, sub, j);
-            return ((ch + ck0) * KS + sub) * a.taps + j;
+        auto slab_of = [&](int q) {
+            const int j = q / KS, sub = q - j * KS;
+            return (chunk * KS + sub) * a.taps + j;
         };
-        auto slab_of = [&](int q) { return slab_at(chunk, q); };
-        auto next_of = [&](int q) { return q + 1 < per_chunk ? slab_at(chunk, q + 1) : slab_at(chunk + 1, 0); };
-        auto at = [&](auto R, auto FIRST, int q) { step(R, FIRST, slab_of(q), next_of(q), chunk, q); };
+        auto at = [&](auto R, auto FIRST, int q) { step(R, FIRST, slab_of(q), chunk, q); };
         __syncthreads();   // X tile #chunk staged by the producers (matches their hand-over barrier)
         if (a.dbg && blockIdx.x == 0 && tid == 0 && chunk < 14) a.dbg[2 + chunk] = clock64() - tick0;
         b0 = rd(xaddr(chunk, 0), 0);
         fold();                           // the previous chunk's chain joins the outer sum (zeros the first time)
         if constexpr (AINP) {
-            stepi(T_{}, slab_of(0), next_of(0), chunk, 0);      // C = 0: a new chain
+            stepi(T_{}, slab_of(0), chunk, 0);      // C = 0: a new chain
             int q = 1;
             for (; q + 2 <= per_chunk; q += 2) {
-                stepi(F_{}, slab_of(q), next_of(q), chunk, q);
-                stepi(F_{}, slab_of(q + 1), next_of(q + 1), chunk, q + 1);
+                stepi(F_{}, slab_of(q), chunk, q);
+                stepi(F_{}, slab_of(q + 1), chunk, q + 1);
             }
-            if (q < per_chunk) stepi(F_{}, slab_of(q), next_of(q), chunk, q);
+            if (q < per_chunk) stepi(F_{}, slab_of(q), chunk, q);
         } else {
             at(F_{}, T_{}, 0);                // C = 0: a new chain
             int q = 1;
@@ -528,33 +477,6 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     if constexpr (FOLD) {
 #pragma unroll
         for (int ni = 0; ni < NW; ++ni) acc[0][ni] = outer[ni] + acc[0][ni];
-    }
-
-    // SK2: the two K halves of a wave tile meet.  Wave (tile, kh) finishes frames [64 kh, 64 kh + 64): it parks the two
-    // frame tiles it does NOT finish in LDS (the X tiles are dead: first barrier), reads its partner's (wave ^ 2) partial
-    // of the tiles it keeps and adds it - P0 + P1, the same bits on either side of the commutative add.
-    constexpr int NWE = SK2 ? NW / 2 : NW;          // 32-frame tiles this wave runs the epilogue of
-    const int fe0 = SK2 ? kh * 64 : wc * WFR;       // ... starting at this frame of the block's tile
-    if constexpr (SK2) {
-        __syncthreads();
-        float4* Ex = Xs;                            // [wave][tile 2][quad 4][lane 64] float4: 8 KiB per wave
-        auto park = [&](const f32x16& v, int i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                DR_CHECK_LDS(Ex + ((wave * 2 + i) * 4 + q) * 64 + lane, xs0, xs1, 111);
-                Ex[((wave * 2 + i) * 4 + q) * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            }
-        };
-        if (kh == 0) { park(acc[0][2], 0); park(acc[0][3], 1); }
-        else { park(acc[0][0], 0); park(acc[0][1], 1); acc[0][0] = acc[0][2]; acc[0][1] = acc[0][3]; }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 p = Ex[(((wave ^ 2) * 2 + i) * 4 + q) * 64 + lane];
-                acc[0][i][4 * q] += p.x; acc[0][i][4 * q + 1] += p.y; acc[0][i][4 * q + 2] += p.z; acc[0][i][4 * q + 3] += p.w;
-            }
     }
 
     const long long tick1 = a.dbg ? clock64() : 0;
@@ -662,8 +584,8 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             }
         }
     #pragma unroll
-        for (int ni = 0; ni < NWE; ++ni) {
-            const int t = t0 + fe0 + ni * 32 + r;
+        for (int ni = 0; ni < NW; ++ni) {
+            const int t = t0 + wc * WFR + ni * 32 + r;
             if constexpr (EPI == EPI_RES_SKIP) {
     #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)

@@ -97,8 +97,6 @@ hipError_t init_kernels();
 hipError_t read_bounds(unsigned long long* out4);
 hipError_t reset_bounds();
 // prec = 0: fp32 X / weights; 1: split-bf16 ("S3") X / weights (EPI_GATE and 1x1 EPI_RES_SKIP only)
-// NI = 1 / 2: blocks of 128 packed rows x 64 / 128 frames; NI = 4 (fp32 EPI_GATE only): HALF tiles of 64 packed rows x
-// 128 frames, K split over the block's wave pairs (gemm_body.h, SK2)
 hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int prec = 0);
 // flexible-width variant (16x16x4 MFMA): block = 128 rows x 32*NJ frames, NJ in {3,5}; fp32, EPI_GATE / 1x1 EPI_RES_SKIP
 hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
@@ -157,9 +155,8 @@ struct StackArgs {
     long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
     StackLayer layer[DR_STACK_MAX_LAYERS];
 };
-// FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames, 4 = half tiles of 64 packed rows x 128 frames (K split
-// over the block's wave pairs).  The caller guarantees NB * stack_group_blocks(FL, Cp, T) <= #CUs and
-// stack_lds_bytes(..) <= 160 KiB.
+// FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames.  The caller guarantees
+// NB * stack_group_blocks(FL, Cp, T) <= #CUs and stack_lds_bytes(..) <= 160 KiB.
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st);
 int stack_tile_frames(int FL);
 int stack_group_blocks(int FL, int Cp, int T);      // blocks per clip evaluation

@@ -7,13 +7,13 @@ namespace dr {
 
 DR_BOUNDS_TU(stack)
 
-// FL = block flavour (all on the 32x32x2 MFMA): 1 / 2 = 128 packed rows x 64 / 128 frames (gemm_body<FL>); 4 = HALF
-// tiles, 64 packed rows x 128 frames with K split over the block's wave pairs (gemm_body<2, .., SK2 = 1>) - for launches
-// that have half a 128 x 128 tile of outputs per CU (16 evaluations x 125 frames, BASELINE config 3's per-GPU shape):
-// every consumer wave then runs the 128-frame flavour's instruction stream instead of the 64-frame one's.
-// (A 160-frame flavour on the 16x16x4 MFMA existed in rounds 2-3 for 640-frame clips: never faster than the per-phase
-// launches there, 92 spilled registers; removed in round 4.)
-// FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavours 1 and 4, on request for flavour 2.
+// FL = block flavour (on the 32x32x2 MFMA): 1 / 2 = 128 packed rows x 64 / 128 frames (gemm_body<FL>).
+// (Two more flavours were built, measured and removed: 160-frame blocks on the 16x16x4 MFMA for 640-frame clips, rounds
+// 2-3 - never faster than the per-phase launches there, 92 spilled registers; and HALF tiles of 64 packed rows x 128
+// frames with K split over the block's wave pairs, round 4, for BASELINE config 3's 16 evaluations x 125 frames - every
+// wave then runs the 128-frame instruction stream, but a 64-row block stages the same X tile for half the MFMAs and the
+// doubled LDS-DMA traffic makes it 4 % slower than 64-frame blocks: profiles/r04_conv_flavour_ab.txt.)
+// FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavour 1, on request for flavour 2.
 template <int FL, int FOLDP = 1>
 __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -25,14 +25,13 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
     const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) StackArgs& s = *sp;
-    static_assert(FL == 1 || FL == 2 || FL == 4, "block flavours");
-    constexpr bool HALF = (FL == 4);
-    constexpr int BN = (FL == 1) ? 64 : 128;
-    constexpr int RP = HALF ? 16 : 32;                     // planes (4 rows each) of the block's resident tile
+    static_assert(FL == 1 || FL == 2, "block flavours");
+    constexpr int BN = 64 * FL;
+    constexpr int RP = 32;                                 // planes (4 rows each) of the block's resident tile
     constexpr int RWL = (BN + 63) / 64;                    // 64-frame segments of a tile row
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int MT = s.Cp >> 6;                              // 128-row M tiles of the 2 Cp packed rows
-    const int MB = HALF ? 2 * MT : MT;                     // blocks per frame tile
+    const int MB = MT;                                     // blocks per frame tile
     const int tps = (s.T + BN - 1) / BN;
     const unsigned gsize = (unsigned)(MB * tps);          // blocks per group
     int mt, nt, grp, member;
@@ -47,9 +46,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     // (a launch whose evaluations are not a multiple of 8 is padded with idle groups - launch_stack - so that the
     // group-per-XCD dealing stays whole: their blocks have nothing to do and touch no counter)
     if (grp >= s.NB) return;
-    const int mh = member % MB;                           // sample (clip evaluation) grp = barrier group
-    mt = HALF ? mh >> 1 : mh;
-    const int hf = HALF ? mh & 1 : 0;                     // HALF: which 64 rows of the M tile
+    mt = member % MB;                                     // sample (clip evaluation) grp = barrier group
     nt = grp * tps + member / MB;
     // A time-out of an earlier launch of this engine that the host has not cleared yet (dr_finish / dr_stack_status):
     // do nothing at all - the chain's remaining launches drain in microseconds and the caller re-runs the sample on
@@ -72,7 +69,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     float4* Rs = reinterpret_cast<float4*>(smem + s.rs_off);
     const int b_ = nt / tps, t0_ = (nt % tps) * BN;
     auto tile_plane = [&](int pl, bool& is_res) -> float* {     // global address of plane pl (4 rows) of the tile, frame 0
-        const int row0 = mt * 128 + hf * 64 + pl * 4;
+        const int row0 = mt * 128 + pl * 4;
         is_res = row0 < s.Cp;
         return is_res ? s.h + (long)b_ * act_bs + (long)(row0 >> 2) * s.T * 4
                       : s.skip + (long)b_ * act_bs + (long)((row0 - s.Cp) >> 2) * s.T * 4;
@@ -136,8 +133,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
-            if constexpr (HALF) gemm_body<2, 2, EPI_GATE, 0, 1, 1, 1>(a, smem, mt, nt, hf);
-            else gemm_body<FL, 1, EPI_GATE, 0, 1, 0, FOLDP>(a, smem, mt, nt, 0);
+            gemm_body<FL, 1, EPI_GATE, 0, 1, FOLDP>(a, smem, mt, nt, 0);
             // The agent-scope acquire the NEXT phase needs (the 1x1 reads g, written by other workgroups, with plain
             // loads through this CU's L1): one producer wave issues it here, while the consumers still contract the
             // last chunk, instead of everyone waiting ~1.7 us for it behind the barrier.  It is valid anywhere
@@ -174,11 +170,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // other's fragment waits and epilogue; 64 fewer live registers in the merged kernel: 204 instead of 256 + 16 B
             // of scratch).  Same k order per output: bit-identical.  Measured at config 2: 1x1 phase 76.9 k -> 73.7 k
             // cycles, chain 883.1 -> 879.3 ms.  The 64-frame flavour keeps four waves: with one 32-frame tile per wave
-            // the phase takes the same cycles at a lower clock (485.4 vs 483.3 ms).  Half tiles: the block's two 32-row
-            // wave tiles x its two 64-frame halves = four waves with two frame tiles each.
-            if constexpr (HALF) {
-                if (wave < 4 && !idle) pw_body<2, 1, 1, 128>(a, mt, nt, hf * 2 + (wave & 1), Rs - hf * 16 * BN, (wave >> 1) * 64);
-            } else if constexpr (FL == 2) {
+            // the phase takes the same cycles at a lower clock (485.4 vs 483.3 ms).
+            if constexpr (FL == 2) {
                 if (!idle) pw_body<2, 1, 1, 128>(a, mt, nt, wave & 3, Rs, (wave >> 2) * 64);
             } else {
                 if (wave < 4 && !idle) pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
@@ -241,13 +234,13 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
 }
 
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st) {
-    if (FL != 1 && FL != 2 && FL != 4) return hipErrorInvalidValue;
+    if (FL != 1 && FL != 2) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
     const int BN = stack_tile_frames(FL), MT = s.Cp >> 6, gsize = stack_group_blocks(FL, s.Cp, s.T);
     const size_t lds = stack_lds_bytes(FL, s.taps, max_dil);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     StackArgs b = s;
-    b.rs_off = (int)(lds - 16 - (size_t)(FL == 4 ? 16 : 32) * BN * 16);
+    b.rs_off = (int)(lds - 16 - (size_t)32 * BN * 16);
     b.lds_bytes = (int)lds;
     const int NBp = xcd_padded_groups(s.NB, gsize, &b.xcd_n);
 #ifdef DR_BOUNDS
@@ -269,19 +262,19 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
     else if (FL == 2 && s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2, 0>), grid, dim3(512), lds, st, b);
-    else hipLaunchKernelGGL((stack_kernel<4>), grid, dim3(512), lds, st, b);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-int stack_tile_frames(int FL) { return FL == 1 ? 64 : 128; }
-// blocks of one clip evaluation (= one barrier group): M tiles (half tiles: twice as many) x frame tiles
+int stack_tile_frames(int FL) { return 64 * FL; }
+// blocks of one clip evaluation (= one barrier group): M tiles x frame tiles
 int stack_group_blocks(int FL, int Cp, int T) {
     const int BN = stack_tile_frames(FL);
-    return (Cp >> 6) * (FL == 4 ? 2 : 1) * ((T + BN - 1) / BN);
+    return (Cp >> 6) * ((T + BN - 1) / BN);
 }
-// the conv's double-buffered X tiles (half tiles: one per K half) + the resident h / skip tile
+// the conv's double-buffered X tiles + the resident h / skip tile
 size_t stack_lds_bytes(int FL, int taps, int max_dil) {
     const int BN = stack_tile_frames(FL), halo = ((taps - 1) / 2) * max_dil;
-    return (size_t)2 * (FL == 4 ? 2 : 1) * 8 * (BN + 2 * halo) * 16 + (size_t)(FL == 4 ? 16 : 32) * BN * 16 + 16;     // + one flag word (16-byte slot)
+    return (size_t)2 * 8 * (BN + 2 * halo) * 16 + (size_t)32 * BN * 16 + 16;     // + one flag word (16-byte slot)
 }
 
 hipError_t init_stack_kernels() {
@@ -289,7 +282,7 @@ hipError_t init_stack_kernels() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipSuccess;
 }
 
 }  // namespace dr

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                              // (the LDS tiles of the previous item / of T3 are free)
             // (same accumulation order as the stack launch that consumes g: blocked unless that is the unblocked 128-frame flavour)
-            if (s.fold) gemm_body<1, 1, EPI_GATE, 0, 1, 0, 1>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
-            else gemm_body<1, 1, EPI_GATE, 0, 1, 0, 0>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
+            if (s.fold) gemm_body<1, 1, EPI_GATE, 0, 1, 1>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
+            else gemm_body<1, 1, EPI_GATE, 0, 1, 0>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
         }
     }
     if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[7] = clock64();

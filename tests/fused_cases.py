@@ -36,15 +36,6 @@ CASES = {
         (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
         (512, 2, 9, 32, 125, "cfdg_ddpm_x0"),       # 64 evaluations: two fused launches (all conditional / all unconditional)
     ],
-    4: [  # half tiles: 64 packed rows x 128 frames, K split over the block's wave pairs (DR_STACK_FL=4, DR_TILE=32:4)
-        (512, 2, 9, 16, 125, "generation_ddpm_x0"),  # BASELINE config 3 per-GPU geometry: 16 evaluations x 16 half tiles = 256 blocks
-        (512, 3, 9, 8, 125, "cfdg_ddpm_x0"),        # guided: the shared first-layer conv stays a 128-row launch / tail part T4
-        (512, 2, 15, 4, 250, "cfdg_ddpm_x0"),       # k = 15 (halo 56), two frame tiles per clip: 8 evaluations x 32 blocks
-        (192, 3, 9, 5, 129, "ddpm_x0"),             # 6 half tiles, one straddling nothing but M tile 1 holding residual AND skip rows; 1 frame in tile 2
-        (64, 3, 9, 3, 40, "cfdg_ddpm_x0"),          # one M tile: half 0 = all residual rows, half 1 = all skip rows; one chunk per K half
-        (128, 2, 3, 8, 65, "generation_ddpm_x0"),   # k = 3, 8 groups (group-per-XCD mapping)
-        (512, 2, 9, 20, 125, "ddpm_x0"),            # 20 evaluations x 16 blocks: two fused launches of 10 samples
-    ],
 }
 
 

@@ -358,13 +358,15 @@ def _denoise64(p, hp, x, spec, t):
 
 
 TRAINED_GEOMETRIES = [
-    # (k, B, T, fused_stack option)     which kernels the launch heuristics pick there
-    (9, 16, 125, 1),       # fused stack, 128-frame blocks (the bench geometry: 32 evaluations)
-    (9, 16, 125, 0),       # per-phase: 128-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
-    (9, 8, 125, 1),        # fused stack, 64-frame blocks
-    (9, 1, 125, 1),        # one clip: LDS-staged kernels with split-K x8 and the ticket reduction
-    (15, 2, 640, 0),       # 16x16-MFMA conv tiles (160-frame blocks), 160-frame 1x1
-    (9, 3, 77, 0),         # ragged: 96-frame flavours / small launches
+    # (k, B, T, fused_stack option, conv accumulates blocked?)     which kernels the launch heuristics pick there
+    (9, 32, 125, 1, False),   # fused stack, 128-frame blocks: 32 evaluations in one forward - the flavour a guided batch of 16 (the
+                              # bench geometry) runs; one fp32 chain per output unless blocked_accumulation = 2 (DR_BLOCKED=2)
+    (9, 16, 125, 1, True),    # fused stack, 64-frame blocks (16 evaluations: BASELINE config 3's shape)
+    (9, 16, 125, 0, True),    # per-phase: 64-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
+    (9, 8, 125, 1, True),     # fused stack, 64-frame blocks, half the chip
+    (9, 1, 125, 1, True),     # one clip: LDS-staged kernels with split-K x8 and the ticket reduction
+    (15, 2, 640, 0, False),   # 16x16-MFMA conv tiles (160-frame blocks, unblocked) or 64-frame tiles cut in K, 160-frame 1x1
+    (9, 3, 77, 0, True),      # ragged: 96-frame flavours / small launches
 ]
 
 
@@ -375,12 +377,19 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
     conditional AND unconditional evaluation of the full-width network (5 layers keep the oracle quick) is compared
     with a FLOAT64 evaluation of the oracle, next to the oracle's own fp32 result: the HIP path (hardware exp2 / rcp in
     the gate, MFMA summation order, split-K tickets, split-bf16 pieces) must be as accurate as the reference's fp32
-    arithmetic - error <= 6x the fp32 oracle's error + 5e-6 of the output range (the MFMA contracts K = 4608 as one
-    k-ordered FMA chain, the CPU library in blocks: a few times its rounding error is legitimate, a wrong saturation
-    or a lost partial is orders of magnitude) - in every kernel flavour."""
+    arithmetic in every kernel flavour.  Where the dilated conv accumulates BLOCKED (round 4: one fp32 chain per
+    32-channel chunk, chunk sums added in a second register set - 64-frame blocks, split-K launches; 128-frame blocks
+    with blocked_accumulation = 2) the bound is 2.5 x the fp32 oracle's error + 5e-6 of the output range (observed
+    <= 1.6 x: the CPU library blocks its K loop too); where a flavour still contracts K = 4608 / 7680 as ONE k-ordered
+    chain (128-frame blocks by default, the 16x16-MFMA flavour) it is 6 x (observed 3 - 3.9 x: legitimate rounding; a
+    wrong saturation or a lost partial is orders of magnitude)."""
+    import os
+    blocked_all = os.environ.get("DR_BLOCKED", "1") == "2"
     s_conv, s_out = scale
     margins = []
-    for (k, B, Tn, fused) in TRAINED_GEOMETRIES:
+    for (k, B, Tn, fused, blocked) in TRAINED_GEOMETRIES:
+        # (the split-bf16 precision keeps one chain per output on 128-frame blocks whatever the option says)
+        bound = 2.5 if (blocked or (blocked_all and k == 9 and precision == "f32")) else 6.0
         hp = dict(R.DEFAULT_HP)
         hp.update(residual_layers=5, kernel_size=k, timesteps=20)
         p = _scaled_params(hp, 11 * k + B, s_conv, s_out)
@@ -402,10 +411,9 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
             e32 = float((ref32.double() - ref64).abs().max())
             ehip = float((got.cpu().double() - ref64).abs().max())
             margins.append((k, B, Tn, fused, uncond, rng, e32, ehip))
-            assert math.isfinite(ehip) and ehip <= 6.0 * e32 + 5e-6 * max(rng, 1.0), \
-                (precision, scale, k, B, Tn, fused, uncond, rng, e32, ehip)
+            assert math.isfinite(ehip) and ehip <= bound * e32 + 5e-6 * max(rng, 1.0), \
+                (precision, scale, k, B, Tn, fused, uncond, bound, rng, e32, ehip)
         del m
-    import os
     log = os.environ.get("DR_PARITY_LOG")
     if log:
         with open(log, "a") as f:
@@ -435,6 +443,7 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
     with torch.no_grad():
         spec = R.frontend(wav, hp, Tn)
     worst = 0.0
+    ratios = []
     for t in range(11, -1, -1):
         z = noise[t] if t > 0 else None
         with torch.no_grad():
@@ -447,8 +456,16 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
         ehip = float((got.cpu().double() - ref64).abs().max())
         worst = max(worst, ehip / (6.0 * e32 + 5e-6 * rng))
         assert math.isfinite(ehip) and ehip <= 6.0 * e32 + 5e-6 * rng, (t, rng, e32, ehip)
+        ratios.append((t, rng, e32, ehip))
         x = ref32
     assert m.engine.fallbacks == 0 and worst > 0.0
+    import os
+    log = os.environ.get("DR_PARITY_LOG")
+    if log:       # the bench geometry's own record: guided steps of 16 clips (128-frame blocks) with the accumulation mode in force
+        mode = "blocked" if os.environ.get("DR_BLOCKED", "1") == "2" else "one-chain"
+        with open(log, "a") as f:
+            for (t, rng, e32, ehip) in ratios:
+                f.write(f"trained_regime[f32,x8/x4,guided-step,B=16,T=125,t={t},conv={mode}] range {rng:.3e} err_fp32_oracle {e32:.3e} err_hip {ehip:.3e}\n")
 
 
 # --------------------------------------------------------------------------------------------
