@@ -46,6 +46,9 @@ VARIANTS = {
     "ablate9": dict(flags=["-DDR_ABLATE=9", "-DDR_FOLD=0"], link=[]),   # measurement build, WRONG results: the producers stage nothing
     # A/B builds of the conv K loop (round 4): the rounds 1-3 loop (one chain per output, two weight-fragment sets) /
     # blocked accumulation off, in-place fragments on / blocked accumulation with two fragment sets
+    # litmus builds (WRONG on purpose): the hand-over without its vmcnt wait / hand-offs without write-through stores
+    "fault1": dict(flags=["-DDR_FAULT=1"], link=[]),
+    "fault2": dict(flags=["-DDR_FAULT=2"], link=[]),
     "r3loop": dict(flags=["-DDR_FOLD=0", "-DDR_AINPLACE=0"], link=[]),
     "nofold": dict(flags=["-DDR_FOLD=0"], link=[]),
     "twosets": dict(flags=["-DDR_AINPLACE=0"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments

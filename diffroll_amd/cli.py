@@ -182,12 +182,20 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
     if S < bs:
         warnings.warn(f"Batch size is larger than total number of audio clips. Forcing batch size to {S}")
         bs = S
+    t_model = time.perf_counter()
     model = make_model(cfg, device)
+    t_engine = time.perf_counter()
+    eng = model.engine                       # dr_create + dr_commit (weight packing, uploads, hoisted tables)
+    torch.cuda.synchronize()
+    t_ready = time.perf_counter()
     os.makedirs(cfg["output_dir"], exist_ok=True)
     t0 = time.perf_counter()
+    batch_s = []
     for bi, lo in enumerate(range(0, S, bs)):
         hi = min(lo + bs, S)
+        tb = time.perf_counter()
         roll = sample_sharded(model, x[lo:hi], waveform[lo:hi], seed=int(cfg["seed"]) + bi)
+        batch_s.append(time.perf_counter() - tb)
         if rank == 0:
             np.save(os.path.join(cfg["output_dir"], f"rolls_batch{bi}.npy"), roll.cpu().numpy())
             model.export_midi(roll, os.path.join(cfg["output_dir"], f"raw_midi_{bi}_"),       # names of predict_step
@@ -198,6 +206,13 @@ def main(argv: List[str] = None, default_task: str = "generation") -> None:
         print(f"{cfg['task']['name']}: {S} clips x {T} frames, {cfg['task']['timesteps']} steps, sampler "
               f"{cfg['task']['sampling']['type']}, {world} GPU(s): {dt:.2f} s ({S * T / dt:.1f} frames/s incl. load "
               f"and capture) -> {cfg['output_dir']}/")
+        # the split a one-shot run pays once (sampling.py:53-73 is one process per batch of clips): see bench.py cold_start
+        ct = eng.cold_times()
+        steady = f", later batches {1e3 * min(batch_s[1:]):.1f} ms" if len(batch_s) > 1 else ""
+        print(f"cold start: model (host) {t_engine - t_model:.2f} s, engine create + commit {t_ready - t_engine:.2f} s "
+              f"(pack {ct[0]:.3f}, upload {ct[1]:.3f}, tables {ct[2]:.3f}), first batch {batch_s[0]:.3f} s "
+              f"(graph capture + instantiate {ct[3]:.4f} s, {int(ct[4])} kernel nodes){steady}; "
+              f"fused-kernel time-outs healed: {eng.fallbacks}")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

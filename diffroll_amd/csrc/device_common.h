@@ -25,6 +25,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DR_AINPLACE
 #define DR_AINPLACE 1
 #endif
+// DR_FAULT (compile-time, LITMUS builds only - results are WRONG on purpose; tests/test_gpu_fused.py, tools/xcd_stress.py):
+//   1 = the producers' LDS-DMA hand-over barrier without its s_waitcnt vmcnt(0) (the round-3 race: consumers may read the
+//       buffer's previous occupant),  2 = the tensors handed to other workgroups stored PLAIN whatever the placement
+//       (no sc1 write-through: a group spread over several XCDs then reads stale lines / stale memory)
+#ifndef DR_FAULT
+#define DR_FAULT 0
+#endif
 // DR_FOLD (compile-time A/B switch, default on): blocked accumulation in gemm_body (0 = one fp32 chain per output over
 // all of K, the rounds 1-3 numerics)
 #ifndef DR_FOLD
@@ -198,7 +205,7 @@ DR_DEVINL float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 // before it signals (stack_kernel's group barrier).  The trailing s_nop covers the store-data hazard.
 template <int COH>
 DR_DEVINL void store_f4(float* dst, const float4 v, const int write_through) {
-    if constexpr (COH) {
+    if constexpr (COH && DR_FAULT != 2) {
         if (write_through) {           // wave-uniform (a kernel-wide mode)
             const f32x4 d = {v.x, v.y, v.z, v.w};
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(d) : "memory");

@@ -187,3 +187,24 @@ def test_split_k_determinism_soak():
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
     assert "every chain bitwise repeatable" in r.stdout, r.stdout[-500:]
+
+
+def test_handoff_litmus_plain_stores_across_xcds_are_caught():
+    """Why the in-launch hand-offs are written the way they are, as a failing experiment: a LITMUS build (-DDR_FAULT=2) stores
+    g / hd with plain stores even when a group's blocks sit on different XCDs.  The XCDs' L2s are not coherent with each
+    other, so the consumers (sc1 loads: L1 bypassed, their own L2 or memory) then read lines the producer's L2 never wrote
+    back - and tools/xcd_stress.py, which compares block mapping 0 (groups spread over all XCDs) with mapping 1 (a group
+    inside one XCD, where plain stores ARE sufficient), must see different rolls.  The production build passes the same
+    comparison bit for bit (test above): relaxed agent-scope counters + s_waitcnt vmcnt(0) order the hand-off, the sc1
+    write-through is what makes the data visible, and nothing weaker than it is.  (The missing-wait race of round 3 has its
+    own litmus build, -DDR_FAULT=1: probabilistic - tools/gpu_soak.sh runs it, DESIGN.md section 5 has the counts.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from diffroll_amd import build
+    lib = build.build(verbose=False, variant="fault2")
+    env = dict(os.environ, DR_LIB=lib, DR_STACK_FL="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "xcd_stress.py"), "--T", "500", "--reps", "12"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
+    assert "mapping 1 repeatable: True" in r.stdout, r.stdout[-2000:]      # inside one XCD plain stores are fine ...
+    assert "RESULT FAIL" in r.stdout, r.stdout[-2000:]                     # ... across XCDs they are not

@@ -1,11 +1,11 @@
 #!/bin/bash
-# round 3, final: the repeatability soaks on the final build (profiles/r03_soak.txt)
+# the repeatability soaks on the final build of a round (profiles/rNN_soak.txt): bash tools/gpu_soak.sh [rNN]
 set -u
 O=gpurun_out/soak; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-S=$O/r03_soak.txt; : > $S
+RD=${1:-r04}; S=$O/${RD}_soak.txt; : > $S
 {
-echo "# repeatability soaks on the round-3 build (one MI355X); every line is a tool's own summary"
+echo "# repeatability soaks on the $RD build (one MI355X); every line is a tool's own summary"
 echo "## tools/fused_soak.py --chains 30 --config 2   (30 x 200 fused launches + 30 x 200 tail launches, same seed: bitwise equal rolls, no time-out)"
 timeout 600 python tools/fused_soak.py --chains 30 --config 2 2>&1 | tail -3
 echo "## tools/fused_soak.py --chains 30 --config 3"
@@ -13,12 +13,10 @@ timeout 600 python tools/fused_soak.py --chains 30 --config 3 2>&1 | tail -3
 echo "## tools/determinism_soak.py 600   (split-K path: small launches, every chain twice)"
 timeout 900 python tools/determinism_soak.py 600 2>&1 | tail -3
 echo "## tools/xcd_stress.py: block mapping 0 (groups spread over the XCDs) must reproduce mapping 1 bit for bit"
-for fl in 0 5; do for T in 500 640; do
-  echo "# DR_STACK_FL=$fl --T $T --reps 40"
-  if [ $fl = 5 ]; then export DR_STACK_FL=5; else unset DR_STACK_FL; fi
-  timeout 600 python tools/xcd_stress.py --T $T --B 4 --reps 40 2>&1 | tail -2
-done; done
-unset DR_STACK_FL
+for T in 500 640; do
+  echo "# DR_STACK_FL=2 --T $T --reps 40"
+  DR_STACK_FL=2 timeout 600 python tools/xcd_stress.py --T $T --B 4 --reps 40 2>&1 | tail -2
+done
 echo "# --T 250 --B 8 --reps 40 (64-frame flavour)"; timeout 600 python tools/xcd_stress.py --T 250 --B 8 --reps 40 2>&1 | tail -2
 echo "# --T 500 --chain 20 --reps 10 (whole chains, tail kernel)"; timeout 900 python tools/xcd_stress.py --T 500 --B 4 --chain 20 --reps 10 2>&1 | tail -2
 echo "## part-filled launches (split-K beyond one resident round): whole captured chains twice, bitwise"
@@ -40,5 +38,15 @@ for B, T in ((3, 125), (5, 125), (6, 125), (10, 125), (12, 125), (20, 125), (1, 
 print(f"part-filled chains: {n} repeats of 9 geometries, {bad} differ; fallbacks {m.engine.fallbacks}")
 PY
 echo "# --T 125 --B 9 --reps 40 (padded launch, 9 guided clips)"; timeout 600 python tools/xcd_stress.py --T 125 --B 9 --reps 40 2>&1 | tail -2
+echo "## LITMUS builds (WRONG on purpose): the same stress must FAIL.  -DDR_FAULT=1 = the hand-over barrier without its s_waitcnt vmcnt(0) (the round-3 race), -DDR_FAULT=2 = hand-offs with plain stores across XCDs"
+for v in fault1 fault2; do
+  L=$(python -m diffroll_amd.build --variant=$v | tail -1)
+  for i in 1 2 3 4 5 6 7 8 9 10; do
+    echo "# $v run $i: DR_STACK_FL=2 --T 640 --reps 24"
+    # (fault1: hipcc still inserts the wait by itself in most kernels of this build - tools/isa_audit.py -DDR_FAULT=1 - and
+    # leaves it out of stack_kernel<2, 1>, the 128-frame flavour with blocked accumulation: that is the one to stress)
+    DR_BLOCKED=2 DR_LIB=$L DR_STACK_FL=2 timeout 600 python tools/xcd_stress.py --T 640 --B 4 --reps 24 2>&1 | grep -E "RESULT|mapping 1 repeatable"
+  done
+done
 } >> $S 2>&1
 cat $S
