@@ -265,6 +265,9 @@ def main():
                     help="multi-rank runs: also create a C-ABI communicator (dr_comm_create) and compare dr_gather with "
                          "torch's all-gather (always done in 1-rank groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accumulation", choices=("auto", "blocked"), default="auto",
+                    help="accumulation order of the dilated conv: auto = blocked where it is free (default), blocked = everywhere "
+                         "it exists (+1.3 %% on 128-frame blocks; DESIGN.md 2)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the time-to-first-roll subprocesses (configs 1 and 2)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
@@ -298,6 +301,7 @@ def main():
     T = Ls // hp["hop_length"]
     inp_t = [T // 4, T // 2] if sampler == "inpainting_ddpm_x0" else None
     model = build_model(device, hp=hp, sampler=sampler, inpainting_t=inp_t)
+    model.accumulation = args.accumulation
     # synthetic inputs, resident in HBM; global sample index = rank * B + b
     g = torch.Generator().manual_seed(1000 + rank)
     wav = (0.1 * torch.randn(B, Ls, generator=g)).to(device)
@@ -351,7 +355,8 @@ def main():
                                "weights, Philox noise, front-end + chain + gather + D2H per step",
                    "baseline_config": args.config, "batch_per_gpu": B, "frames_per_clip": T, "diffusion_steps": S,
                    "kernel_size": cfg["k"], "sampler": sampler, "w": W_CFG if cfg["evals"] == 2 else None,
-                   "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True},
+                   "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True,
+                   "conv_accumulation": args.accumulation},
         "dist": launch.dist_info(dist),
         "fused_fallbacks": 0,
     }

@@ -70,7 +70,12 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     constexpr int WROWS = MI * 32;                // rows per wave
     constexpr int WFR = NW * 32;                  // frames per wave
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    // COH (the persistent kernels call this body once per phase inside a loop): everything this call derives from the lane
+    // index must be computed INSIDE the call.  Without the opaque barrier the compiler hoists the per-lane address
+    // arithmetic of every phase body out of the phase loop - dozens of registers that then live through the K loops of the
+    // other phases (stack_kernel<2> with blocked accumulation: 256 VGPRs + 232 B of scratch before).
+    if constexpr (COH) asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long tick0 = a.dbg ? clock64() : 0;   // measurement hook (null in production launches)
@@ -454,6 +459,9 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         if (a.dbg && blockIdx.x == 0 && tid == 0 && chunk < 14) a.dbg[2 + chunk] = clock64() - tick0;
         b0 = rd(xaddr(chunk, 0), 0);
         fold();                           // the previous chunk's chain joins the outer sum (zeros the first time)
+        // (the first step's pinned schedule starts HERE: without the fence its first sched group adopts the reads of b0
+        // above, and every fragment read of the step is issued one group late - right in front of the MFMAs that wait for it)
+        if constexpr (FOLD) __builtin_amdgcn_sched_barrier(0);
         if constexpr (AINP) {
             stepi(T_{}, slab_of(0), chunk, 0);      // C = 0: a new chain
             int q = 1;
@@ -752,7 +760,8 @@ DR_DEVINL void pw_body(const GemmArgs& a, const int mt, const int nt, const int 
     // the CU's L1 turns that into one L2 request instead of four (measured: with L1-bypassing sc1 loads the phase
     // ran 2x slower) - the fused kernel therefore invalidates the L1 once, in the barrier before this phase.
     constexpr int XAUX = 0;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    if constexpr (COH) asm volatile("" : "+v"(lane));      // (as gemm_body: no per-lane value of this call may be hoisted out of a phase loop)
     const int r = lane & 31, hi = lane >> 5;
     const long long tick0 = a.dbg ? clock64() : 0;
 

@@ -104,7 +104,8 @@ class ClassifierFreeDiffRoll(nn.Module):
                  generation_filter=0.0,
                  device=None,
                  precision="f32",
-                 beta_schedule="linear"):
+                 beta_schedule="linear",
+                 accumulation="auto"):
         super().__init__()
         if condition not in ("fixed", "trainable_spec"):
             if condition == "trainable_z":
@@ -188,6 +189,12 @@ class ClassifierFreeDiffRoll(nn.Module):
             raise ValueError(f"spec_args.n_mels={sa.get('n_mels')} differs from n_mels={n_mels} (the conditioner's input width)")
         self._device = device
         self.precision = precision          # 'f32' (exact, default) | 'bf16x3' (opt-in split precision)
+        # accumulation order of the dilated conv (an extension): 'auto' = blocked (one fp32 chain per
+        # 32-channel chunk, like a CPU library's K-blocked GEMM) wherever that is free; 'blocked' = in every fp32 flavour
+        # that has a blocked form, +1.3 % on 128-frame blocks (16 guided clips per GPU)
+        if accumulation not in ("auto", "blocked"):
+            raise ValueError("accumulation is 'auto' or 'blocked'")
+        self.accumulation = accumulation
         self._engine: Optional[Engine] = None
         self._dirty = True
         self._fe_key = None
@@ -218,6 +225,10 @@ class ClassifierFreeDiffRoll(nn.Module):
             self._fe_key = None
         if self._engine.precision != self.precision:
             self._engine.set_precision(self.precision)
+        want = 2 if self.accumulation == "blocked" else 1
+        if getattr(self._engine, "_blocked", None) != want and not (want == 1 and "DR_BLOCKED" in __import__("os").environ):
+            self._engine.set_option("blocked_accumulation", want)
+            self._engine._blocked = want
         return self._engine
 
     # schedule vectors, exposed like the reference's attributes (task/diffusion.py:239-256)

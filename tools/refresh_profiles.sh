@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence under profiles/ - run ON THE GPU BOX:
-#     gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r03 gpurun_out/prof'
+#     gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r04 gpurun_out/prof'
 # then copy gpurun_out/prof/<round>_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter set per
 # pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
 set -u
-RD=${1:-r03}
+RD=${1:-r04}
 R=$PWD
 OUT=$R/${2:-gpurun_out/prof}
 mkdir -p "$OUT"
@@ -43,7 +43,10 @@ rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
 timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
 timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"
 timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
-timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" > "$OUT/${RD}_scale_table.txt" 2>&1
+timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" --scale-json "$OUT/${RD}_scale.json" > "$OUT/${RD}_scale_table.txt" 2>&1
+# time-to-first-roll: round-3 behaviour re-enabled ("before") next to the current build, fresh process each
+{ for c in 1 2; do DR_PACK_THREADS=1 DR_S3_EAGER=1 timeout 300 python -m diffroll_amd.coldstart --config $c --json 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "before (serial packing, eager split-bf16 packings)", "record": /; s/$/}/'; done
+  for c in 1 2; do timeout 300 python -m diffroll_amd.coldstart --config $c --json 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "now", "record": /; s/$/}/'; done; } > "$OUT/${RD}_cold_start.json"
 head -14 "$OUT/${RD}_kernel_stats.txt"
 cat "$OUT"/${RD}_dominant_cfg*_traffic.json
 grep -A8 "stack_kernel" "$OUT/${RD}_stack_pmc_mfma.txt" | head -12

@@ -20,11 +20,12 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--level", type=int, default=1, help="fused_stack option value (2 = forced, e.g. with DR_STACK_FL=5)")
     ap.add_argument("--batch", type=int, default=0, help="override the configuration's batch (clips per GPU)")
+    ap.add_argument("--k", type=int, default=0, help="override the configuration's kernel size (taps per 32-channel chunk)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = bench.CONFIGS[args.config]
     hp = dict(bench.HP)
-    hp.update(kernel_size=cfg["k"], timesteps=cfg["S"])
+    hp.update(kernel_size=args.k or cfg["k"], timesteps=cfg["S"])
     T = cfg["L"] // 512
     m = bench.build_model(dev, hp=hp, sampler=cfg["sampler"])
     eng = m.engine
