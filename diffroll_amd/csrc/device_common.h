@@ -143,7 +143,9 @@ DR_DEVINL void split3(float x, uint32_t (&pc)[3]) {
 }
 // store 4 consecutive channels (one C/D register quad) of frame t as the three bf16 pieces:
 // dst = S3 tensor base of this sample; the quad is the low (half = 0) or high 8 bytes of its plane8 unit
-DR_DEVINL void store_s3_quad(float* dst, const float (&v)[4], int row0, int t, int T, int P8) {
+// COH / write_through: as store_f4 - 8-byte write-through (sc1) stores for tensors handed to other workgroups of the launch
+template <int COH = 0>
+DR_DEVINL void store_s3_quad(float* dst, const float (&v)[4], int row0, int t, int T, int P8, const int write_through = 0) {
     uint32_t pc[4][3];
 #pragma unroll
     for (int e = 0; e < 4; ++e) split3(v[e], pc[e]);
@@ -155,6 +157,14 @@ DR_DEVINL void store_s3_quad(float* dst, const float (&v)[4], int row0, int t, i
         w.x = (pc[0][p] >> 16) | pc[1][p];
         w.y = (pc[2][p] >> 16) | pc[3][p];
         char* q = reinterpret_cast<char*>(dst) + (((long)p * P8 + plane8) * T + t) * 16 + half * 8;
+        if constexpr (COH && DR_FAULT != 2) {
+            if (write_through) {       // wave-uniform
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 d = {w.x, w.y};
+                asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(d) : "memory");
+                continue;
+            }
+        }
         *reinterpret_cast<uint2*>(q) = w;
     }
 }

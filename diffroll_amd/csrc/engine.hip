@@ -608,7 +608,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     int stack_from = -1;                   // first phase run by the fused kernel (-1: none)
     int stack_ni = 0, stack_chunks = 1;    // flavour, and how many sample chunks the evaluation is launched in
     bool fused_step = false;
-    if (e->opt_stack && prec == 0 && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
+    // (the split-bf16 precision has its own flavour of the kernel: 128-channel S3 chunks in the 1x1 phases need Cp % 128 == 0)
+    static const int stack3 = getenv("DR_STACK3") ? atoi(getenv("DR_STACK3")) : 1;
+    if (e->opt_stack && (prec == 0 || (stack3 && Cp % 128 == 0)) && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
         // Flavours 1 / 2 (128 packed rows x 64 / 128 frames per block) are chosen automatically; DR_STACK_FL=n pins one
@@ -639,7 +641,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             const int bn = stack_tile_frames(fl);
             const long gsize = stack_group_blocks(fl, Cp, T);                           // blocks per sample
             const long cap = std::min<long>(e->n_cus, 1024) / gsize;                    // samples per launch
-            if (cap < 1 || stack_lds_bytes(fl, e->K, maxdil) > 160 * 1024) continue;
+            if (cap < 1 || (prec ? stack3_lds_bytes(fl, e->K, maxdil) : stack_lds_bytes(fl, e->K, maxdil)) > 160 * 1024) continue;
             const long chunks = (NB + cap - 1) / cap;
             if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
@@ -658,7 +660,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         // fused step (option "fused_tail"): everything behind the stack launch - skip / output projection, update, and
         // for a chain the next step's input projection and (guided) shared first-layer conv - is one tail launch,
         // when the evaluation is ONE fused launch of the 32x32-MFMA flavours
-        fused_step = stack_ni && stack_chunks == 1 && e->opt_tail && !tsel;
+        fused_step = stack_ni && stack_chunks == 1 && e->opt_tail && !tsel && prec == 0;      // (the tail kernel is fp32 only)
     }
     const bool use_tail = fused_step && tail != nullptr;
     // input projection + relu (model/diffwave.py:667-668) - unless the previous step's tail kernel already wrote h / hd
@@ -686,6 +688,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             const int nb = NB / stack_chunks + (ck < NB % stack_chunks ? 1 : 0);      // balanced chunk sizes
             StackArgs sa{};
             sa.h = e->h + b0 * act_n; sa.hd = e->hd + b0 * act_n; sa.g = e->g + b0 * act_n; sa.skip = e->skip + b0 * act_n;
+            if (prec) { sa.hd = e->hd3 + b0 * (act_n + act_n / 2); sa.g = e->g3 + b0 * (act_n + act_n / 2); }      // the S3 tensors
             sa.d2 = e->d_dtab + (tsel ? 0 : (size_t)t * L * Cp);
             sa.tsel = tsel ? tsel + b0 : nullptr; sa.d2_ts = (long)L * Cp;
             sa.zero = zero_vec();
@@ -702,7 +705,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             for (int l = 0; l < L; ++l) {
                 const LayerW& w = e->layers[l];
                 StackLayer& y = sa.layer[l];
-                y.conv_w = w.conv_w; y.conv_b = w.conv_b;
+                y.conv_w = prec ? w.conv_w3 : w.conv_w; y.conv_b = w.conv_b;
                 y.conv_b2 = zero_spec ? w.conv_b_z : w.conv_b_u;
                 y.cond2 = nullptr;
                 if (e->cond_tr && !zero_spec) { y.cond2 = e->cond_tr + (size_t)l * 2 * Cp * T; y.conv_b2 = w.conv_b; }
@@ -710,11 +713,11 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 // without any keeps a readable pointer: the kernel prefetches, then ignores it)
                 y.cond = e->cond ? e->cond + (size_t)l * e->fe_B * 2 * Cp * T + (b0 < n_cond ? (size_t)b0 * c_bs : 0)
                                  : e->cond_dummy;
-                y.out_w = w.out_w; y.out_b = w.out_b; y.dil = w.dil;
+                y.out_w = prec ? w.out_w3 : w.out_w; y.out_b = w.out_b; y.dil = w.dil;
             }
             const bool timed = e->prof && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
-            HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st));
+            HIPCHK(e, launch_stack(sa, stack_ni, maxdil, st, prec));
             e->stack_launches += 1;
             e->unverified = true;
             if (timed) {
@@ -727,7 +730,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                                std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
                                std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) +
                                (stack_chunks > 1 ? ", " + std::to_string(stack_chunks) + " sample chunks" : "") +
-                               ((stack_ni != 2 || e->opt_blocked >= 2) ? ", blocked accumulation" : ", one fp32 chain per output") + ")";
+                               (prec ? (stack_ni == 1 ? ", split-bf16, blocked accumulation" : ", split-bf16, one chain per output")
+                                     : ((stack_ni != 2 || e->opt_blocked >= 2) ? ", blocked accumulation" : ", one fp32 chain per output")) + ")";
             }
             b0 += nb;
         }

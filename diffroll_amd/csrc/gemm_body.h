@@ -149,7 +149,8 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rrecs, 0x00020000);
                 const int voff = (t0 + seg * 64 + lane) * 16;
                 DR_CHECK_LDS(Rs + pl * BN + seg * 64 + lane, xs1, rs1, 102);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, voff, 0, 0, 0);
+                // (COH: the tile was written by THIS workgroup in an earlier phase of the same launch - bypass the L1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, voff, 0, 0, COH ? 16 : 0);
             }
         }
 #if DR_ABLATE != 9
@@ -649,7 +650,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                         for (int e = 0; e < 4; ++e) o[e] = v0[e] * v0[e] + v1[e] * v1[e];
                     }
                     if (a.out_s3 & 1) {   // g for the split-bf16 1x1 kernel
-                        store_s3_quad(a.Y + (long)be * a.y_bs, o, c0, t, a.T, a.y_rows >> 3);
+                        store_s3_quad<COH>(a.Y + (long)be * a.y_bs, o, c0, t, a.T, a.y_rows >> 3, a.wt_store);
                     } else {
                         float* dst = a.Y + (long)be * a.y_bs + (long)(c0 >> 2) * a.y_ps + (long)t * a.y_fs;
                         store_f4<COH>(dst, make_float4(o[0], o[1], o[2], o[3]), a.wt_store);
@@ -677,7 +678,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                                     f4arr(ed2[mi][q], dd);
                                     const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
                                     if (a.out_s3 & 2) {
-                                        store_s3_quad(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                        store_s3_quad<COH>(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3, a.wt_store);
                                     } else {
                                         float* dst2 = a.Y2 + (long)be * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
                                         *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);
@@ -706,7 +707,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                                     f4arr(ed2[mi][q], dd);
                                     const float o2[4] = {o[0] + dd[0], o[1] + dd[1], o[2] + dd[2], o[3] + dd[3]};
                                     if (a.out_s3 & 2) {
-                                        store_s3_quad(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3);
+                                        store_s3_quad<COH>(a.Y2 + (long)be * a.y2_bs, o2, p0, t, a.T, a.y_rows >> 3, a.wt_store);
                                     } else {
                                         float* dst2 = a.Y2 + (long)be * a.y2_bs + (long)(p0 >> 2) * a.y_ps + (long)t * a.y_fs;
                                         *reinterpret_cast<float4*>(dst2) = make_float4(o2[0], o2[1], o2[2], o2[3]);

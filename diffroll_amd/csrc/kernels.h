@@ -157,7 +157,9 @@ struct StackArgs {
 };
 // FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames.  The caller guarantees
 // NB * stack_group_blocks(FL, Cp, T) <= #CUs and stack_lds_bytes(..) <= 160 KiB.
-hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st);
+// prec = 1: the split-bf16 flavour (s.hd / s.g = the S3 tensors; Cp % 128 == 0; LDS: stack3_lds_bytes)
+hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st, int prec = 0);
+size_t stack3_lds_bytes(int FL, int taps, int max_dil);
 int stack_tile_frames(int FL);
 int stack_group_blocks(int FL, int Cp, int T);      // blocks per clip evaluation
 size_t stack_lds_bytes(int FL, int taps, int max_dil);

@@ -14,7 +14,12 @@ DR_BOUNDS_TU(stack)
 // wave then runs the 128-frame instruction stream, but a 64-row block stages the same X tile for half the MFMAs and the
 // doubled LDS-DMA traffic makes it 4 % slower than 64-frame blocks: profiles/r04_conv_flavour_ab.txt.)
 // FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavour 1, on request for flavour 2.
-template <int FL, int FOLDP = 1>
+// PREC = 1: the split-bf16 ("S3") precision - s.hd / s.g are the S3 tensors hd3 / g3 ([sample][piece][channel/8][frame][8
+// bf16]); the conv phase is gemm_body<.., PREC = 1> (S3 in, S3 out), the 1x1 phase the LDS-staged S3 GEMM (gemm_body<1, 4,
+// EPI_RES_SKIP, 1>) on the block's 64-frame tile(s), which re-reads its h / skip tile from global every layer (nothing is
+// LDS-resident here: the S3 X tiles of a 128-channel 1x1 chunk need the space); same device code as the per-phase launches
+// of that precision: bit-identical to them.  Needs Cp % 128 == 0.
+template <int FL, int FOLDP = 1, int PREC = 0>
 __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // The arguments are read through the kernarg segment pointer (constant address space: scalar loads at the
@@ -74,7 +79,9 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         return is_res ? s.h + (long)b_ * act_bs + (long)(row0 >> 2) * s.T * 4
                       : s.skip + (long)b_ * act_bs + (long)((row0 - s.Cp) >> 2) * s.T * 4;
     };
-    {
+    if constexpr (PREC) {
+        if (pending_timeout) return;
+    } else {
         typedef __attribute__((address_space(3))) void* lds_ptr;
         const int lane = threadIdx.x & 63;
         for (int i = wave; i < RP * RWL; i += 8) {
@@ -127,6 +134,41 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         a.MT = MT; a.NB = s.NB; a.T = s.T; a.alpha = 1.f; a.ksplit = 1;
         a.x_bs = act_bs; a.x_ps = (long)s.T * 4; a.x_fs = 4; a.x_planes = P; a.kchunks = s.Cp >> 5;
         a.y_bs = act_bs; a.y_ps = (long)s.T * 4; a.y_fs = 4; a.y_rows = s.Cp;
+        if constexpr (PREC) {
+            const long s3_bs = act_bs + act_bs / 2;          // per-sample size of an S3 tensor (4-byte units)
+            if ((p & 1) == 0) {
+                a.Wp = ly.conv_w; a.bias = ly.conv_b; a.bias2 = ly.conv_b2;
+                a.X = s.hd; a.x_bs = s3_bs; a.x_piece = (long)(s.Cp >> 3) * s.T * 4; a.x_planes = s.Cp >> 3;
+                a.taps = s.taps; a.dil = ly.dil;
+                a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
+                a.Y = s.g; a.y_bs = s3_bs; a.out_s3 = 1;
+                gemm_body<FL, 1, EPI_GATE, 1, 1, FOLDP>(a, smem, mt, nt, 0);
+            } else {
+                a.Wp = ly.out_w; a.bias = ly.out_b;
+                a.X = s.g; a.x_bs = s3_bs; a.x_piece = (long)(s.Cp >> 3) * s.T * 4; a.x_planes = s.Cp >> 3;
+                a.taps = 1; a.dil = 1;
+                a.Y = s.h;
+                const bool last = (l + 1 == s.L);
+                if (!last) {
+                    a.Y2 = s.hd; a.y2_bs = s3_bs; a.out_s3 = 2;
+                    a.d2 = s.d2 + (long)(l + 1) * s.Cp; a.tsel = s.tsel; a.d2_ts = s.d2_ts;
+                }
+                a.skip = s.skip; a.s_bs = act_bs; a.skip_init = (l == 0);
+                const bool idle = last && mt < (s.Cp >> 7);
+                // the block's BN-frame tile as 64-frame tiles of the S3 1x1 body (one hand-over chunk = 128 channels)
+                const int tps64 = (s.T + 63) >> 6;
+                const int b_ = nt / tps, ti = nt % tps;
+#pragma unroll 1
+                for (int half = 0; half < BN / 64; ++half) {
+                    const int t64 = ti * (BN / 64) + half;
+                    if (half) {          // (the LDS regions of the previous call are free once every wave is past its epilogue)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                    }
+                    if (!idle && t64 < tps64) gemm_body<1, 4, EPI_RES_SKIP, 1, 1>(a, smem, mt, b_ * tps64 + t64, 0);
+                }
+            }
+        } else
         if ((p & 1) == 0) {
             a.Wp = ly.conv_w; a.bias = ly.conv_b; a.bias2 = ly.conv_b2;
             a.X = s.hd; a.taps = s.taps; a.dil = ly.dil;
@@ -205,7 +247,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
         s.dbg[121] = wall_clock64();
     }
     // write the resident tile back: skip always (the skip projection reads it next), h only when layers remain
-    {
+    if constexpr (!PREC) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int lane = threadIdx.x & 63;
@@ -233,11 +275,12 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     }
 }
 
-hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st) {
+hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st, int prec) {
     if (FL != 1 && FL != 2) return hipErrorInvalidValue;
+    if (prec && (s.Cp & 127)) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
     const int BN = stack_tile_frames(FL), MT = s.Cp >> 6, gsize = stack_group_blocks(FL, s.Cp, s.T);
-    const size_t lds = stack_lds_bytes(FL, s.taps, max_dil);
+    const size_t lds = prec ? stack3_lds_bytes(FL, s.taps, max_dil) : stack_lds_bytes(FL, s.taps, max_dil);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     StackArgs b = s;
     b.rs_off = (int)(lds - 16 - (size_t)32 * BN * 16);
@@ -259,6 +302,11 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
 #endif
     (void)MT;
     const dim3 grid((unsigned)(gsize * NBp));
+    if (prec) {
+        if (FL == 1) hipLaunchKernelGGL((stack_kernel<1, 1, 1>), grid, dim3(512), lds, st, b);
+        else hipLaunchKernelGGL((stack_kernel<2, 0, 1>), grid, dim3(512), lds, st, b);
+        return hipGetLastError();
+    }
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
     else if (FL == 2 && s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2, 0>), grid, dim3(512), lds, st, b);
@@ -266,6 +314,10 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st)
     return hipGetLastError();
 }
 int stack_tile_frames(int FL) { return 64 * FL; }
+// split-bf16 flavour: max over its two phase bodies (conv: S3 X tiles; 1x1: 128-channel S3 X tiles + the 64-frame h / skip tile)
+size_t stack3_lds_bytes(int FL, int taps, int max_dil) {
+    return std::max(gemm_lds_bytes(FL, 1, taps, max_dil, 1, EPI_GATE), gemm_lds_bytes(1, 4, 1, 1, 1, EPI_RES_SKIP)) + 16;
+}
 // blocks of one clip evaluation (= one barrier group): M tiles x frame tiles
 int stack_group_blocks(int FL, int Cp, int T) {
     const int BN = stack_tile_frames(FL);
@@ -282,6 +334,8 @@ hipError_t init_stack_kernels() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipSuccess;
 }
 

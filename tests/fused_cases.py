@@ -37,18 +37,26 @@ CASES = {
         (512, 2, 9, 32, 125, "cfdg_ddpm_x0"),       # 64 evaluations: two fused launches (all conditional / all unconditional)
     ],
 }
+# the split-bf16 flavours of the fused kernel (precision="bf16x3"; channel counts that are multiples of 128)
+CASES_S3 = {
+    1: [(128, 4, 9, 2, 125, "cfdg_ddpm_x0"), (128, 3, 15, 5, 129, "ddpm_x0"), (512, 2, 9, 8, 128, "generation_ddpm_x0"),
+        (384, 2, 9, 3, 300, "ddpm_x0"), (512, 3, 15, 16, 64, "cfdg_ddpm_x0"), (512, 2, 9, 20, 125, "cfdg_ddpm_x0")],
+    2: [(512, 3, 9, 16, 125, "cfdg_ddpm_x0"), (512, 2, 9, 8, 250, "cfdg_ddpm_x0"), (512, 2, 15, 16, 200, "generation_ddpm_x0"),
+        (384, 2, 9, 20, 129, "ddpm_x0"), (128, 2, 9, 6, 65, "cfdg_ddpm_x0")],
+}
 
 
 def main():
+    prec = "bf16x3" if len(sys.argv) > 2 and sys.argv[2] == "bf16x3" else "f32"
     ni = int(sys.argv[1])
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     out = []
-    for (C, layers, k, B, Tn, sampler) in CASES[ni]:
+    for (C, layers, k, B, Tn, sampler) in (CASES_S3 if prec == "bf16x3" else CASES)[ni]:
         hp = dict(R.DEFAULT_HP)
         hp.update(residual_channels=C, residual_layers=layers, kernel_size=k, timesteps=6)
         p = R.synthetic_params(hp, seed=C + k)
-        m = make_model(hp, p, sampler=sampler, w=0.5)
+        m = make_model(hp, p, sampler=sampler, w=0.5, precision=prec)
         g = torch.Generator().manual_seed(B * 1000 + Tn)
         wav = 0.1 * torch.randn(B, max(Tn * 512, 2048), generator=g)
         x = torch.randn(B, 1, Tn, 88, generator=g)
@@ -94,7 +102,7 @@ def main():
         eng.set_option("fused_tail", 1)
         out.append(rec)
         del m
-    if ni == 1:
+    if ni == 1 and prec == "f32":
         # the remaining conditioner variants of the gate epilogue inside the fused kernel: the learned unconditional
         # spectrogram of condition='trainable_spec' (cond2, model/diffwave.py:656-658) and the spec == 0 branch of
         # cfdg_ddim_x0 (task/diffusion.py:1027-1055)

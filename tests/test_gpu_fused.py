@@ -36,18 +36,20 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", ["1", "2", "2b"])
+@pytest.mark.parametrize("ni", ["1", "2", "2b", "1s", "2s"])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
     pinned to the flavours the fused kernel is built from (the overrides are read once per process).  "2b" = the
-    128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations)."""
+    128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations);
+    "1s" / "2s" = the split-bf16 flavours (precision="bf16x3": S3 hand-offs, LDS-staged 1x1 phases, no tail kernel)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     blocked = ni.endswith("b")
-    ni = int(ni.rstrip("b"))
+    s3 = ni.endswith("s")
+    ni = int(ni.rstrip("bs"))
     env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni), DR_STACK_FL=str(ni),
                DR_BLOCKED="2" if blocked else "1")
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)], env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)] + (["bf16x3"] if s3 else []), env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("FUSED_CASES ")][-1]
@@ -61,7 +63,7 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
                 # (an evaluation that needs several fused launches - sample chunks - keeps the separate tail launches)
                 # (DR_TAIL=0 - a forced-mode run of the suite - only changes the DEFAULT: runs that set the option carry "tail")
                 env_off = "tail" not in run and os.environ.get("DR_TAIL", "1") == "0"
-                want_tail = run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1 and not env_off
+                want_tail = run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1 and not env_off and not s3
                 assert (run["tail_launches"] >= 1) == want_tail, rec
 
 
