@@ -265,9 +265,9 @@ def main():
                     help="multi-rank runs: also create a C-ABI communicator (dr_comm_create) and compare dr_gather with "
                          "torch's all-gather (always done in 1-rank groups)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--accumulation", choices=("auto", "blocked"), default="auto",
-                    help="accumulation order of the dilated conv: auto = blocked where it is free (default), blocked = everywhere "
-                         "it exists (+1.3 %% on 128-frame blocks; DESIGN.md 2)")
+    ap.add_argument("--accumulation", choices=("auto", "blocked", "single_chain"), default="auto",
+                    help="accumulation order of the dilated conv: auto = blocked = one fp32 chain per 32-channel chunk in every fp32 "
+                         "flavour (default); single_chain = 128-frame blocks keep one chain over all of K (-0.5 %%; DESIGN.md 2)")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the time-to-first-roll subprocesses (configs 1 and 2)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
@@ -356,7 +356,7 @@ def main():
                    "baseline_config": args.config, "batch_per_gpu": B, "frames_per_clip": T, "diffusion_steps": S,
                    "kernel_size": cfg["k"], "sampler": sampler, "w": W_CFG if cfg["evals"] == 2 else None,
                    "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True,
-                   "conv_accumulation": args.accumulation},
+                   "conv_accumulation": "blocked" if args.accumulation == "auto" else args.accumulation},
         "dist": launch.dist_info(dist),
         "fused_fallbacks": 0,
     }

@@ -133,7 +133,7 @@ struct dr_engine {
                                         // blocks still read it); the chain ping-pongs between this and its roll buffer
     int64_t stack_fallbacks = 0;        // time-outs detected by dr_finish: each one switched this engine to per-phase launches
     bool unverified = false;            // persistent launches have been issued since the last check of the time-out flag
-    int opt_blocked = 1;                // option "blocked_accumulation": 1 = where it is free, 2 = in the 128-frame flavours too
+    int opt_blocked = 2;                // option "blocked_accumulation": 2 (default) = every fp32 flavour that has a blocked form, 1 = 128-frame blocks keep one chain per output (-0.5 % per chain, 2-3x the rounding error)
     int opt_rearm = 0;                  // option "fused_rearm": clean chains after a time-out before fusing again (0: never)
     int healed_from = 0;                // the fused_stack value a time-out switched off (0: none pending re-arm)
     int clean_chains = 0;               // chains finished cleanly since that time-out

@@ -49,10 +49,10 @@ namespace dr {
 //   fragment reads; the chunk's first MFMAs take a zero C operand, so nothing is cleared.
 //
 //   FOLDP: blocked accumulation wanted.  It applies to the gated conv (EPI_GATE: the K = taps x C contraction; every other
-//   GEMM of the path has K <= 1056 and keeps one chain, bit-identical to pw_body) and defaults to on where it is free -
-//   64-frame blocks (+0.9 % per config-3 chain); 128-row x 128-frame blocks pay for the second accumulator set (256
-//   registers, a few spilled values per phase in the fused kernel: +4 % per config-2 chain) and take it only on request
-//   (engine option "blocked_accumulation" = 2).  profiles/r04_conv_flavour_ab.txt.
+//   GEMM of the path has K <= 1056 and keeps one chain, bit-identical to pw_body).  Cost, with the fold pinned behind the
+//   hand-over barrier (see fold()): +0.6 % per config-3 chain on 64-frame blocks, +0.2-0.6 % per config-2 chain on 128-row x
+//   128-frame blocks (208 registers with the in-place fragment refresh below) - on by default in both (engine option
+//   "blocked_accumulation": 1 = 128-frame blocks keep one chain).  profiles/r04_conv_flavour_ab.txt.
 template <int NI, int KS, int EPI, int PREC, int COH, int FOLDP = (NI == 1)>
 DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
     constexpr int BN = 64 * NI;
@@ -202,6 +202,12 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         if constexpr (FOLD) {
 #pragma unroll
             for (int ni = 0; ni < NW; ++ni) outer[ni] = outer[ni] + acc[0][ni];
+            // The adds happen HERE.  Their results are only needed after the K loop, and left alone the compiler sinks
+            // them to the bottom of the chunk - which keeps the previous chain alive through the whole chunk in a THIRD
+            // register set (16*NW copies per chunk behind the last MFMAs; at NW = 4 also what pushed the kernel into
+            // scratch).  An opaque use pins them in front of the chunk's first MFMAs, which then reuse acc's registers.
+#pragma unroll
+            for (int ni = 0; ni < NW; ++ni) asm volatile("" : "+v"(outer[ni]));
         }
     };
 
@@ -479,7 +485,9 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                 at(F_{}, F_{}, q + 1);
             }
             if (q < per_chunk) at(T_{}, F_{}, q);
-            else wA = wB;                     // (an odd number of steps ends in role A: the next fragments sit in set B)
+            else wA = wB;                     // (an odd number of steps ends in role A: the next fragments sit in set B.
+                                              // Swapping the roles across chunks instead - two copies of the chunk body -
+                                              // was measured: 505 vs 483 ms per config-3 chain, spills at 128 frames)
         }
     }
 

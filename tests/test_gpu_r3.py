@@ -360,7 +360,8 @@ def _denoise64(p, hp, x, spec, t):
 TRAINED_GEOMETRIES = [
     # (k, B, T, fused_stack option, conv accumulates blocked?)     which kernels the launch heuristics pick there
     (9, 32, 125, 1, False),   # fused stack, 128-frame blocks: 32 evaluations in one forward - the flavour a guided batch of 16 (the
-                              # bench geometry) runs; one fp32 chain per output unless blocked_accumulation = 2 (DR_BLOCKED=2)
+                              # bench geometry) runs; blocked in f32 unless blocked_accumulation = 1 (DR_BLOCKED=1); the split-bf16
+                              # precision keeps one chain per output there
     (9, 16, 125, 1, True),    # fused stack, 64-frame blocks (16 evaluations: BASELINE config 3's shape)
     (9, 16, 125, 0, True),    # per-phase: 64-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
     (9, 8, 125, 1, True),     # fused stack, 64-frame blocks, half the chip
@@ -378,13 +379,14 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
     with a FLOAT64 evaluation of the oracle, next to the oracle's own fp32 result: the HIP path (hardware exp2 / rcp in
     the gate, MFMA summation order, split-K tickets, split-bf16 pieces) must be as accurate as the reference's fp32
     arithmetic in every kernel flavour.  Where the dilated conv accumulates BLOCKED (round 4: one fp32 chain per
-    32-channel chunk, chunk sums added in a second register set - 64-frame blocks, split-K launches; 128-frame blocks
-    with blocked_accumulation = 2) the bound is 2.5 x the fp32 oracle's error + 5e-6 of the output range (observed
-    <= 1.6 x: the CPU library blocks its K loop too); where a flavour still contracts K = 4608 / 7680 as ONE k-ordered
-    chain (128-frame blocks by default, the 16x16-MFMA flavour) it is 6 x (observed 3 - 3.9 x: legitimate rounding; a
-    wrong saturation or a lost partial is orders of magnitude)."""
+    32-channel chunk, chunk sums added in a second register set - every 32x32-MFMA flavour in f32 by default; 128-frame
+    blocks keep one chain in the split-bf16 precision and with blocked_accumulation = 1) the bound is 2.5 x the fp32
+    oracle's error + 5e-6 of the output range (observed <= 1.6 x: the CPU library blocks its K loop too); where a
+    flavour still contracts K = 4608 / 7680 as ONE k-ordered chain (the 16x16-MFMA flavour; 128-frame blocks in the
+    cases above) it is 6 x (observed 3 - 3.9 x: legitimate rounding; a wrong saturation or a lost partial is orders of
+    magnitude)."""
     import os
-    blocked_all = os.environ.get("DR_BLOCKED", "1") == "2"
+    blocked_all = os.environ.get("DR_BLOCKED", "2") == "2"
     s_conv, s_out = scale
     margins = []
     for (k, B, Tn, fused, blocked) in TRAINED_GEOMETRIES:
@@ -415,10 +417,11 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
                 (precision, scale, k, B, Tn, fused, uncond, bound, rng, e32, ehip)
         del m
     log = os.environ.get("DR_PARITY_LOG")
+    _acc = "blocked" if blocked_all else "single_chain"
     if log:
         with open(log, "a") as f:
             for (k, B, Tn, fused, uncond, rng, e32, ehip) in margins:
-                f.write(f"trained_regime[{precision},x{s_conv:g}/x{s_out:g},k={k},B={B},T={Tn},fused={fused},uncond={int(uncond)}] "
+                f.write(f"trained_regime[{precision},x{s_conv:g}/x{s_out:g},k={k},B={B},T={Tn},fused={fused},uncond={int(uncond)},acc={_acc}] "
                         f"range {rng:.3e} err_fp32_oracle {e32:.3e} err_hip {ehip:.3e}\n")
 
 
@@ -444,6 +447,9 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
         spec = R.frontend(wav, hp, Tn)
     worst = 0.0
     ratios = []
+    import os
+    blocked = os.environ.get("DR_BLOCKED", "2") == "2"      # (DR_BLOCKED=1: the rounds 1-3 numerics, for the record)
+    bound = 2.5 if blocked else 6.0
     for t in range(11, -1, -1):
         z = noise[t] if t > 0 else None
         with torch.no_grad():
@@ -454,15 +460,14 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
         rng = max(float(ref64.abs().max()), 1.0)
         e32 = float((ref32.double() - ref64).abs().max())
         ehip = float((got.cpu().double() - ref64).abs().max())
-        worst = max(worst, ehip / (6.0 * e32 + 5e-6 * rng))
-        assert math.isfinite(ehip) and ehip <= 6.0 * e32 + 5e-6 * rng, (t, rng, e32, ehip)
+        worst = max(worst, ehip / (bound * e32 + 5e-6 * rng))
+        assert math.isfinite(ehip) and ehip <= bound * e32 + 5e-6 * rng, (t, bound, rng, e32, ehip)
         ratios.append((t, rng, e32, ehip))
         x = ref32
     assert m.engine.fallbacks == 0 and worst > 0.0
-    import os
     log = os.environ.get("DR_PARITY_LOG")
     if log:       # the bench geometry's own record: guided steps of 16 clips (128-frame blocks) with the accumulation mode in force
-        mode = "blocked" if os.environ.get("DR_BLOCKED", "1") == "2" else "one-chain"
+        mode = "blocked" if blocked else "single_chain"
         with open(log, "a") as f:
             for (t, rng, e32, ehip) in ratios:
                 f.write(f"trained_regime[f32,x8/x4,guided-step,B=16,T=125,t={t},conv={mode}] range {rng:.3e} err_fp32_oracle {e32:.3e} err_hip {ehip:.3e}\n")

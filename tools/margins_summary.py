@@ -2,6 +2,7 @@
 """Aggregate a DR_PARITY_LOG file (one line per maxdiff() comparison of the GPU suite, plus the trained-regime battery's
 records) into the table committed under profiles/:  python tools/margins_summary.py <margins.txt> > profiles/rNN_parity_margins.txt"""
 import collections
+import re
 import statistics
 import sys
 
@@ -31,17 +32,19 @@ def main():
         print()
         print("# Trained-weight regime (tests/test_gpu_r3.py: dilated-conv / conditioner weights x s_conv, 1x1 weights x s_out;")
         print("# 5-layer full-width net): error against a FLOAT64 evaluation of the oracle, next to the fp32 oracle's own error.")
-        print("# The bound asserted: err_hip <= 6 x err_fp32_oracle + 5e-6 x range.")
+        print("# The bound asserted: err_hip <= b x err_fp32_oracle + 5e-6 x range, b = 2.5 where the dilated conv accumulates\n# in blocks (every 32x32-MFMA flavour in f32 by default), 6 where a flavour keeps one chain over all of K (16x16-MFMA tiles,\n# 128-frame blocks in the split-bf16 precision, or with DR_BLOCKED=1 = third column 'single_chain').")
         worst = collections.defaultdict(lambda: (0.0, ""))
         for line in trained:
             tag = line.split("]")[0] + "]"
             f = line.split()
             rng, e32, ehip = float(f[2]), float(f[4]), float(f[6])
             key = tag.split(",")[0].replace("trained_regime[", "") + "," + tag.split(",")[1]
+            m = re.search(r"(?:acc|conv)=(\w+)", tag)
+            key += "," + (m.group(1) if m else "auto")
             ratio = ehip / max(e32, 1e-30)
             if ratio > worst[key][0]:
                 worst[key] = (ratio, f"range {rng:.2e} err_fp32_oracle {e32:.2e} err_hip {ehip:.2e}  {tag}")
-        print(f"{'precision, scaling':28s} {'worst err_hip / err_fp32_oracle':>32s}   where")
+        print(f"{'precision, scaling, accum.':28s} {'worst err_hip / err_fp32_oracle':>32s}   where")
         for key, (ratio, where) in sorted(worst.items()):
             print(f"{key:28s} {ratio:32.2f}   {where}")
         print(f"# {len(trained)} (geometry, conditional / unconditional) evaluations in all")
