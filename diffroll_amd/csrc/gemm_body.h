@@ -164,10 +164,12 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             // was slower than their own first weight fragments - observed with cross-XCD hand-offs).  Hence explicit.
             // The consumers' matching barrier opens their chunk; only then may the OTHER buffer be refilled (the
             // consumers finished reading it before they arrived here).
-#if DR_FAULT != 1           // (litmus build 1: the wait left out - what rounds 1-2 shipped in the persistent kernels)
+#if DR_FAULT != 1
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
             __syncthreads();
+#else                       // litmus build 1: the hand-over WITHOUT the wait - a bare s_barrier, so that hipcc's own fence
+            __builtin_amdgcn_s_barrier();       // handling cannot put it back (which kernels of rounds 1-2 had it was luck)
+#endif
 #if DR_ABLATE != 9
             if (chunk + 1 < c1) issue(chunk + 1);
 #endif

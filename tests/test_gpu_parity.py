@@ -38,7 +38,7 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inpainting_f=None, precision="f32"):
+def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inpainting_f=None, precision="f32", **extra):
     from diffroll_amd import ClassifierFreeDiffRoll
     m = ClassifierFreeDiffRoll(
         residual_channels=hp["residual_channels"], unconditional=False, condition="fixed",
@@ -50,7 +50,7 @@ def make_model(hp, params, sampler="cfdg_ddpm_x0", w=0.5, inpainting_t=None, inp
                        normalized=True, pad_mode="reflect"),
         spec_dropout=0.1, inpainting_t=inpainting_t, inpainting_f=inpainting_f,
         timesteps=hp["timesteps"], beta_start=hp["beta_start"], beta_end=hp["beta_end"],
-        training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, precision=precision)
+        training={"mode": "x_0"}, sampling={"type": sampler, "w": w}, precision=precision, **extra)
     m.load_state_dict(params)
     return m
 

@@ -473,6 +473,35 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
                 f.write(f"trained_regime[f32,x8/x4,guided-step,B=16,T=125,t={t},conv={mode}] range {rng:.3e} err_fp32_oracle {e32:.3e} err_hip {ehip:.3e}\n")
 
 
+
+def test_accumulation_kwarg_selects_the_conv_numerics():
+    """accumulation='auto' and 'blocked' are the same kernels (bit-equal rolls); 'single_chain' contracts all of K as one
+    fp32 chain on 128-frame blocks (the rounds 1-3 numerics): other bits, the same answer to fp32 round-off; any other
+    value is rejected by the constructor."""
+    import os
+    if "DR_BLOCKED" in os.environ:
+        pytest.skip("DR_BLOCKED overrides the 'auto' default")
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_layers=3, timesteps=20)
+    p = R.synthetic_params(hp, seed=5)
+    g = torch.Generator().manual_seed(9)
+    B, Tn = 32, 125                     # 32 evaluations x 125 frames: the fused stack on 128-frame blocks
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    t = torch.tensor(7).repeat(B)
+    out = {}
+    for acc in ("auto", "blocked", "single_chain"):
+        m = make_model(hp, p, accumulation=acc)
+        out[acc] = m(x, wav, t)[0].cpu()
+        assert m.engine.fallbacks == 0
+        del m
+    assert torch.equal(out["auto"], out["blocked"])
+    assert not torch.equal(out["single_chain"], out["blocked"])
+    assert float((out["single_chain"] - out["blocked"]).abs().max()) <= 1e-5
+    with pytest.raises(ValueError):
+        make_model(hp, p, accumulation="pairwise")
+
+
 # --------------------------------------------------------------------------------------------
 # the FFT kernel directly against torch.stft
 # --------------------------------------------------------------------------------------------

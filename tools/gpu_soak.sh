@@ -44,9 +44,8 @@ for v in fault1 fault2; do
   for i in 1 2 3 4 5 6 7 8 9 10; do
     echo "# $v run $i: DR_STACK_FL=2 --T 640 --reps 24"
     DR_BLOCKED=2 DR_LIB=$L DR_STACK_FL=2 timeout 600 python tools/xcd_stress.py --T 640 --B 4 --reps 24 2>&1 | grep -E "RESULT|mapping 1 repeatable"
-    # (fault1: hipcc inserts the wait by itself in most kernels of that build - which ones changes with every edit of the K
-    # loop: tools/isa_audit.py -DDR_FAULT=1 lists them; on the final round-4 build it is missing in tail_kernel only, so the
-    # whole-chain form, which runs the tail kernel, is stressed as well)
+    # (fault1 = a bare s_barrier in the producers: tools/isa_audit.py -DDR_FAULT=1 finds the missing wait in every kernel
+    # with an LDS-DMA hand-over; the whole-chain form runs the tail kernel too)
     if [ $v = fault1 ]; then
       echo "# $v run $i: --T 500 --chain 12 --reps 6 (tail kernel)"
       DR_LIB=$L timeout 600 python tools/xcd_stress.py --T 500 --B 4 --chain 12 --reps 6 2>&1 | grep -E "RESULT|mapping 1 repeatable"
