@@ -29,7 +29,7 @@ def main():
     # the dominant kernel of the run: the fused stack where it is used, else the conv + gate kernel (EPI 3) of either
     # MFMA flavour
     import re
-    kern = max((k for k in cf if "stack_kernel" in k or re.search(r"gemm_kernel<\d, 1, 3, 0>|gemm16_kernel<\d, 1, 3>", k)),
+    kern = max((k for k in cf if "stack_kernel" in k or re.search(r"gemm_kernel<\d, 1, 3, 0(?:, \d)?>|gemm16_kernel<\d, 1, 3>", k)),
                key=lambda k: sum(cf[k]["FETCH_SIZE"]))
     mean = lambda v: sum(v) / len(v)      # noqa: E731
     fetch_kb = mean(cf[kern]["FETCH_SIZE"])
