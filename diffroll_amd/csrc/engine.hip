@@ -418,13 +418,16 @@ double split_cost(long blocks, int bn, double pen, int MT, int taps) {
     const double us_per_frame = p.us_unsplit / ((double)((blocks + 255) / 256) * bn);      // us of one frame column of a full-K tile
     return 1.05 * pen * p.us / us_per_frame;
 }
-Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool allow16) {
+// wide32: the 96 / 160-frame flavours of the 32x32 conv kernel (n = 3 / 5; fp32 gated conv with blocked accumulation) may be
+// used - they take the place of the 16x16 kernels of those widths, which have no blocked form (option blocked_accumulation = 2)
+Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool allow16, bool wide32 = false) {
     static const char* forced = getenv("DR_TILE");     // tuning experiments: "32:2", "16:5", ... (if it fits)
     const int halo = ((taps - 1) / 2) * dil;
     struct Cand { int flavor, n, bn; double pen; };
-    const Cand cands[] = {{0, 2, 128, 1.0}, {1, 5, 160, 1.04}, {1, 3, 96, 1.04}, {0, 1, 64, 1.0}};
+    const Cand cands[] = {{0, 2, 128, 1.0}, {0, 5, 160, 1.04}, {1, 5, 160, 1.04}, {0, 3, 96, 1.04}, {1, 3, 96, 1.04}, {0, 1, 64, 1.0}};
     auto feasible = [&](const Cand& c) {
         if (c.flavor == 1 && (!allow16 || prec != 0)) return false;
+        if (c.flavor == 0 && (c.n == 3 || c.n == 5) && (!wide32 || prec != 0 || epi != EPI_GATE || taps == 1)) return false;
         const int ks = (taps == 1) ? 2 : 1;
         const size_t lds = (c.flavor == 0)
             ? gemm_lds_bytes(c.n, (taps == 1 && c.n == 1) ? 4 : ks, taps, dil, prec, epi)
@@ -442,7 +445,7 @@ Tile pick_tile(int MT, int NB, int T, int taps, int dil, int prec, int epi, bool
         if (!feasible(c)) continue;
         const long blocks = (long)MT * NB * ((T + c.bn - 1) / c.bn);
         double cost = (double)((blocks + 255) / 256) * c.bn * c.pen;
-        if (c.flavor == 0 && prec == 0 && epi == EPI_GATE && taps > 1 && allow16)
+        if (c.flavor == 0 && c.n <= 2 && prec == 0 && epi == EPI_GATE && taps > 1 && allow16)
             cost = std::min(cost, split_cost(blocks, c.bn, c.pen, MT, taps));
         if (cost < best_cost - 1e-9) { best_cost = cost; best = Tile{c.flavor, c.n}; }
     }
@@ -765,8 +768,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             // writes both gated outputs (conditioner of b / constant unconditional bias).  Bit-identical.
             const bool dual = (l == 0 && bmod > 0 && NB == 2 * bmod && n_cond == bmod);
             if (dual) { a.NB = bmod; a.dual = bmod; }
-            const Tile tile = dual ? pick_tile(Cp / 64, bmod, T, e->K, w.dil, prec, EPI_GATE, false)
-                                   : pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true);
+            const Tile tile = dual ? pick_tile(Cp / 64, bmod, T, e->K, w.dil, prec, EPI_GATE, false, e->opt_blocked >= 2)
+                                   : pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true, e->opt_blocked >= 2);
             if (e->stack_dbg_on && l + 1 == L) a.dbg = e->stack_dbg + 64;
             const bool timed = e->prof && !dual && stack_from < 0 && e->prof_used < e->prof_events.size();
             if (timed) HIPCHK(e, hipEventRecord(e->prof_events[e->prof_used].first, st));
@@ -1863,7 +1866,7 @@ int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, vo
     }
     a.dbg = e->dbg_ticks;
     allow_splitk(e, a);
-    HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, e->prec, EPI_GATE, true), (hipStream_t)stream, e->prec));
+    HIPCHK(e, launch_tiled(a, EPI_GATE, pick_tile(Cp / 64, NB, T, e->K, w.dil, e->prec, EPI_GATE, true, e->opt_blocked >= 2), (hipStream_t)stream, e->prec));
     return DR_OK;
 }
 

@@ -340,16 +340,17 @@ static hipError_t init_gemm16() {
 
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
     const int halo = ((taps - 1) / 2) * dil;
-    const int FW = 64 * NI + 2 * halo;
-    return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * 64 * NI * 16 : 0);
+    const int BN = gemm_block_frames(NI);
+    const int FW = BN + 2 * halo;
+    return (size_t)2 * (prec ? 12 : 8) * KS * FW * 16 + (epi == EPI_RES_SKIP ? (size_t)32 * BN * 16 : 0);
 }
 
 KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n) {
     static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
     static const long max_blocks_env = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 0;
     const long max_blocks = max_blocks_env ? max_blocks_env : (prec ? 256 : 2048);
-    const int BN = 64 * NI;
-    const double t_full = (double)kchunks * taps * 16.0 * (2 * NI) * 69.0 / 2400.0;
+    const int BN = gemm_block_frames(NI);
+    const double t_full = (double)kchunks * taps * 16.0 * (BN / 32) * 69.0 / 2400.0;
     auto cost = [&](int ks) {
         return (double)((tiles * ks + 255) / 256) * t_full / ks + (ks > 1 ? 4.0 + ks : 0.0);
     };
@@ -365,7 +366,7 @@ KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, i
 
 template <int NI, int KS, int EPI, int PREC>
 static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
-    const int BN = 64 * NI;
+    const int BN = gemm_block_frames(NI);
     const int tps = (a.T + BN - 1) / BN;
     const size_t lds = gemm_lds_bytes(NI, KS, a.taps, a.dil, PREC, EPI);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -390,8 +391,13 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
-    return hipGetLastError();
+    if constexpr (NI == 3 || NI == 5) {       // 96 / 160-frame blocks: the gated conv with blocked accumulation only
+        hipLaunchKernelGGL((gemm_kernel<NI, 1, EPI_GATE, 0, 1>), grid, dim3(512), lds, s, b);
+        return hipGetLastError();
+    } else {
+        hipLaunchKernelGGL((gemm_kernel<NI, KS, EPI, PREC>), grid, dim3(512), lds, s, b);
+        return hipGetLastError();
+    }
 }
 
 template <int NI, int KS, int EPI, int PREC>
@@ -426,6 +432,8 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<5, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<3, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;
     if ((e = init_tail_kernels()) != hipSuccess) return e;
     if ((e = init_stack_kernels()) != hipSuccess) return e;
@@ -468,6 +476,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int pr
         if (KS == 4) return launch_gemm_ni<2, 4>(a, epi, s);
         return KS == 2 ? launch_gemm_ni<2, 2>(a, epi, s) : launch_gemm_ni<2, 1>(a, epi, s);
     }
+    if (NI == 5 && epi == EPI_GATE && KS == 1) return launch_gemm_t<5, 1, EPI_GATE, 0>(a, s);
+    if (NI == 3 && epi == EPI_GATE && KS == 1) return launch_gemm_t<3, 1, EPI_GATE, 0>(a, s);
     return hipErrorInvalidValue;
 }
 

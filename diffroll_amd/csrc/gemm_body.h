@@ -55,7 +55,14 @@ namespace dr {
 //   "blocked_accumulation": 1 = 128-frame blocks keep one chain).  profiles/r04_conv_flavour_ab.txt.
 template <int NI, int KS, int EPI, int PREC, int COH, int FOLDP = (NI == 1)>
 DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
-    constexpr int BN = 64 * NI;
+    // NI = 1 / 2: 64 / 128-frame blocks (2 / 4 32-frame MFMA tiles per consumer wave); NI = 3 / 5: THREE / FIVE tiles = 96 /
+    // 160-frame blocks, the dilated conv only (640-frame geometries: 4 x 160-frame blocks per clip, 8 evaluations x 4 x 8 M
+    // tiles = 256 blocks; ragged lengths: 96) - fp32 with blocked accumulation, in place of the 16x16-MFMA kernels of those
+    // widths, which have no blocked form
+    constexpr int NW = (NI == 3 || NI == 5) ? NI : 2 * NI;    // 32-frame MFMA tiles per wave
+    constexpr int BN = 32 * NW;
+    static_assert(NI == 1 || NI == 2 || ((NI == 3 || NI == 5) && EPI == EPI_GATE && PREC == 0 && KS == 1 && FOLDP == 1),
+                  "block widths: 64, 128; 96, 160 (conv)");
     constexpr int XP = (PREC ? 12 : 8) * KS;      // 16-byte rows per X tile
     // Consumer wave arrangement: 4 (M) x 1 (N) - every wave owns 32 distinct rows x all 64*NI frames of the
     // block, so no two waves issue the same A-fragment loads (a CU's vector-memory path is the stressed
@@ -66,7 +73,6 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     constexpr bool PAIRED = (EPI == EPI_GATE || EPI == EPI_POWER);
     constexpr int WNC = 1;                        // consumer waves along N
     constexpr int MI = 1;                         // 32-row MFMA tiles per wave
-    constexpr int NW = 2 * NI;                    // 32-frame MFMA tiles per wave
     constexpr int WROWS = MI * 32;                // rows per wave
     constexpr int WFR = NW * 32;                  // frames per wave
 
@@ -418,7 +424,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // next step's group g right behind the group's last MFMA (one buffer load per group: prefetch distance three
     // groups = 48 MFMAs) - ONE fragment set instead of two, which is what lets the second accumulator set of the
     // blocked accumulation (64 registers at NW = 4) live in the K loop without spilling; no roles, no per-chunk copy.
-    constexpr bool AINP = DR_AINPLACE && (NI == 2) && FOLD;
+    constexpr bool AINP = DR_AINPLACE && (NI == 2 || NI == 5) && FOLD;
     auto load_ag = [&](int slab, int g) -> float4 {
         DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 112, slab, NS);
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);

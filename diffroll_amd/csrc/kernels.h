@@ -104,6 +104,9 @@ hipError_t launch_gemm16(const GemmArgs& a, int epi, int NJ, hipStream_t s);
 // (NW in {2,3,4,5}), 256 threads
 hipError_t launch_pointwise(const GemmArgs& a, int NW, hipStream_t s);
 hipError_t launch_pointwise_ksplit(const GemmArgs& a, int NW, hipStream_t s);   // under-filled launches: 32-row tiles, K split over the block's waves
+// frames per block of gemm_kernel<NI, ...>: 64 / 128 (NI = 1 / 2), 96 / 160 (NI = 3 / 5: that many 32-frame MFMA tiles per
+// consumer wave, the gated conv only)
+inline int gemm_block_frames(int NI) { return (NI == 3 || NI == 5) ? 32 * NI : 64 * NI; }
 size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 // THE split-K decision of gemm_kernel launches (the launcher takes it; the engine's tile choice prices a launch with it,
 // so the estimate and the launch cannot disagree): for `tiles` output tiles of 128 rows x 64 NI frames, `nchunks` hand-over
