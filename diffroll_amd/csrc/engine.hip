@@ -733,7 +733,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                                std::to_string(e->K) + " + conditioner + gate and 1x1 + residual/skip, phases " +
                                std::to_string(p0) + ".." + std::to_string(p1 - 1) + " of " + std::to_string(2 * L) +
                                (stack_chunks > 1 ? ", " + std::to_string(stack_chunks) + " sample chunks" : "") +
-                               (prec ? (stack_ni == 1 ? ", split-bf16, blocked accumulation" : ", split-bf16, one chain per output")
+                               (prec ? ((stack_ni != 2 || e->opt_blocked >= 2) ? ", split-bf16, blocked accumulation" : ", split-bf16, one chain per output")
                                      : ((stack_ni != 2 || e->opt_blocked >= 2) ? ", blocked accumulation" : ", one fp32 chain per output")) + ")";
             }
             b0 += nb;

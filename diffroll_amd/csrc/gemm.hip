@@ -385,9 +385,9 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     b.xcd_n = pick_xcd_mapping(a.MT, NT, wbytes, xbytes);
     DR_CHECK_EXTENTS(b, EPI, PREC, "gemm_kernel");
     // the 128-frame gated conv exists with and without blocked accumulation (GemmArgs::fold128)
-    if constexpr (NI == 2 && KS == 1 && EPI == EPI_GATE && PREC == 0) {
+    if constexpr (NI == 2 && KS == 1 && EPI == EPI_GATE) {
         if (a.fold128) {
-            hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, 0, 1>), grid, dim3(512), lds, s, b);
+            hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, PREC, 1>), grid, dim3(512), lds, s, b);
             return hipGetLastError();
         }
     }
@@ -432,6 +432,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<5, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<3, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;

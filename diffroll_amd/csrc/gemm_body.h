@@ -203,9 +203,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #pragma unroll
         for (int e = 0; e < 16; ++e) outer[ni][e] = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // (not in the 128-frame split-bf16 flavour: its K loop holds 96 B-fragment registers - 3 pieces x 4 tiles x 2 groups
-    // in flight - and has no room for a second accumulator set; that opt-in mode keeps one chain per output there)
-    constexpr bool FOLD = DR_FOLD && FOLDP && EPI == EPI_GATE && !(PREC == 1 && NI == 2);
+    constexpr bool FOLD = DR_FOLD && FOLDP && EPI == EPI_GATE;
     auto fold = [&]() {
         if constexpr (FOLD) {
 #pragma unroll

@@ -304,6 +304,7 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st,
     const dim3 grid((unsigned)(gsize * NBp));
     if (prec) {
         if (FL == 1) hipLaunchKernelGGL((stack_kernel<1, 1, 1>), grid, dim3(512), lds, st, b);
+        else if (s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1, 1>), grid, dim3(512), lds, st, b);
         else hipLaunchKernelGGL((stack_kernel<2, 0, 1>), grid, dim3(512), lds, st, b);
         return hipGetLastError();
     }
@@ -336,6 +337,7 @@ hipError_t init_stack_kernels() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipSuccess;
 }
 

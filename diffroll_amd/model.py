@@ -190,7 +190,7 @@ class ClassifierFreeDiffRoll(nn.Module):
         self._device = device
         self.precision = precision          # 'f32' (exact, default) | 'bf16x3' (opt-in split precision)
         # accumulation order of the dilated conv (an extension): 'auto' = 'blocked' = one fp32 chain per
-        # 32-channel chunk, chunk sums added up separately - like a CPU library's K-blocked GEMM - in every fp32 flavour;
+        # 32-channel chunk, chunk sums added up separately - like a CPU library's K-blocked GEMM - in every flavour;
         # 'single_chain' = 128-frame blocks (16 guided clips per GPU) and the 96 / 160-frame flavours (640-frame rolls) contract
         # all of K as one chain, the rounds 1-3 numerics: 0.2-0.8 % faster, 2-3x the rounding error against float64
         if accumulation not in ("auto", "blocked", "single_chain"):

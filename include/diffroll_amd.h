@@ -309,8 +309,7 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          32-channel block, block sums added up in block order, in every fp32 kernel flavour (against
  *                          float64 the error is 1.0-1.6x the CPU fp32 reference's in the trained-weight regime);
  *                          1 = the 128-frame blocks and the 96 / 160-frame flavours contract all of K as ONE chain (the
- *                          numerics of ABI <= 7: 0.2-0.8 % faster, 3.0-3.9x).  The split-bf16 precision keeps one chain on
- *                          128-frame blocks either way.
+ *                          numerics of ABI <= 7: 0.2-0.8 % faster, 3.0-3.9x; 1.0 % faster in the split-bf16 precision).
  *   "fused_rearm"      [0] n > 0: after a time-out has switched this engine to per-phase launches, go back to the fused
  *                          kernels once n chains in a row have finished cleanly (a time-out caused by a transient
  *                          tenant - a profiler, a second process that has left - then costs n chains at the per-phase

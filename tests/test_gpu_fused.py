@@ -36,17 +36,18 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", ["1", "2", "2b", "1s", "2s"])
+@pytest.mark.parametrize("ni", ["1", "2", "2b", "1s", "2s", "2sb"])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
     pinned to the flavours the fused kernel is built from (the overrides are read once per process).  "2b" = the
     128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations);
-    "1s" / "2s" = the split-bf16 flavours (precision="bf16x3": S3 hand-offs, LDS-staged 1x1 phases, no tail kernel)."""
+    "1s" / "2s" / "2sb" = the split-bf16 flavours (precision="bf16x3": S3 hand-offs, LDS-staged 1x1 phases, no tail
+    kernel; "2sb": 128-frame blocks with blocked accumulation)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    blocked = ni.endswith("b")
-    s3 = ni.endswith("s")
-    ni = int(ni.rstrip("bs"))
+    blocked = "b" in ni
+    s3 = "s" in ni
+    ni = int(ni[0])
     env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni), DR_STACK_FL=str(ni),
                DR_BLOCKED="2" if blocked else "1")
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)] + (["bf16x3"] if s3 else []), env=env,

@@ -1124,6 +1124,8 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
         assert worst <= ATOL_FWD, (var, worst)
     # the 32x32-MFMA conv flavours (64 / 96 / 128 / 160-frame blocks) all accumulate in the same 32-channel blocks: with K
     # splitting and the fused stack out of the way they produce the same bits
+    if os.environ.get("DR_BLOCKED", "2") != "2":
+        return              # (blocked_accumulation = 1: 128-frame blocks keep one chain, 96 / 160 fall back to the 16x16 kernels)
     hashes = {}
     for t in ("32:1", "32:2", "32:3", "32:5"):
         env = dict(os.environ, DR_TILE=t, DR_KSPLIT_MAX="1", DR_STACK="0")

@@ -360,8 +360,7 @@ def _denoise64(p, hp, x, spec, t):
 TRAINED_GEOMETRIES = [
     # (k, B, T, fused_stack option, conv accumulates blocked?)     which kernels the launch heuristics pick there
     (9, 32, 125, 1, False),   # fused stack, 128-frame blocks: 32 evaluations in one forward - the flavour a guided batch of 16 (the
-                              # bench geometry) runs; blocked in f32 unless blocked_accumulation = 1 (DR_BLOCKED=1); the split-bf16
-                              # precision keeps one chain per output there
+                              # bench geometry) runs; blocked unless blocked_accumulation = 1 (DR_BLOCKED=1)
     (9, 16, 125, 1, True),    # fused stack, 64-frame blocks (16 evaluations: BASELINE config 3's shape)
     (9, 16, 125, 0, True),    # per-phase: 64-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
     (9, 8, 125, 1, True),     # fused stack, 64-frame blocks, half the chip
@@ -381,8 +380,8 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
     with a FLOAT64 evaluation of the oracle, next to the oracle's own fp32 result: the HIP path (hardware exp2 / rcp in
     the gate, MFMA summation order, split-K tickets, split-bf16 pieces) must be as accurate as the reference's fp32
     arithmetic in every kernel flavour.  Where the dilated conv accumulates BLOCKED (round 4: one fp32 chain per
-    32-channel chunk, chunk sums added in a second register set - every 32x32-MFMA flavour in f32 by default; 128-frame
-    blocks keep one chain in the split-bf16 precision and with blocked_accumulation = 1) the bound is 2.5 x the fp32
+    32-channel chunk, chunk sums added in a second register set - every flavour the default options select, in both
+    precisions; 128-frame blocks keep one chain with blocked_accumulation = 1) the bound is 2.5 x the fp32
     oracle's error + 5e-6 of the output range (observed <= 1.6 x: the CPU library blocks its K loop too); where a
     flavour still contracts K = 4608 / 7680 as ONE k-ordered chain (the 16x16-MFMA flavour; 128-frame blocks in the
     cases above) it is 6 x (observed 3 - 3.9 x: legitimate rounding; a wrong saturation or a lost partial is orders of
@@ -392,10 +391,9 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
     s_conv, s_out = scale
     margins = []
     for (k, B, Tn, fused, blocked) in TRAINED_GEOMETRIES:
-        # (the split-bf16 precision keeps one chain per output on 128-frame blocks whatever the option says)
         if blocked == "wide":
             blocked = blocked_all or precision != "f32"
-        bound = 2.5 if (blocked or (blocked_all and k == 9 and precision == "f32")) else 6.0
+        bound = 2.5 if (blocked or (blocked_all and k == 9)) else 6.0
         hp = dict(R.DEFAULT_HP)
         hp.update(residual_layers=5, kernel_size=k, timesteps=20)
         p = _scaled_params(hp, 11 * k + B, s_conv, s_out)

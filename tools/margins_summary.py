@@ -32,7 +32,7 @@ def main():
         print()
         print("# Trained-weight regime (tests/test_gpu_r3.py: dilated-conv / conditioner weights x s_conv, 1x1 weights x s_out;")
         print("# 5-layer full-width net): error against a FLOAT64 evaluation of the oracle, next to the fp32 oracle's own error.")
-        print("# The bound asserted: err_hip <= b x err_fp32_oracle + 5e-6 x range, b = 2.5 where the dilated conv accumulates\n# in blocks (every 32x32-MFMA flavour in f32 by default), 6 where a flavour keeps one chain over all of K (16x16-MFMA tiles,\n# 128-frame blocks in the split-bf16 precision, or with DR_BLOCKED=1 = third column 'single_chain').")
+        print("# The bound asserted: err_hip <= b x err_fp32_oracle + 5e-6 x range, b = 2.5 where the dilated conv accumulates\n# in blocks (every flavour the default options select), 6 where a flavour keeps one chain over all of K (DR_BLOCKED=1 =\n# third column 'single_chain': 128-frame blocks, and the 16x16-MFMA conv kernels of the 96 / 160-frame widths).")
         worst = collections.defaultdict(lambda: (0.0, ""))
         for line in trained:
             tag = line.split("]")[0] + "]"
