@@ -315,7 +315,8 @@ class Engine:
         return n.value, ms.value, fl.value, buf.value.decode()
 
     def set_option(self, name: str, value: int):
-        """'fused_stack' / 'fused_stack_xcd' / 'stack_ticks' (include/diffroll_amd.h: dr_set_option)."""
+        """Integer options of the engine - 'fused_stack', 'fused_tail', 'fused_rearm', 'blocked_accumulation', ... :
+        include/diffroll_amd.h, dr_set_option.  Unknown names and values out of range raise ValueError."""
         self._check(self.lib.dr_set_option(self.h, name.encode(), int(value)))
 
     def stack_status(self, n_ticks: int = 0):

@@ -496,6 +496,9 @@ def test_accumulation_kwarg_selects_the_conv_numerics():
         m = make_model(hp, p, accumulation=acc)
         out[acc] = m(x, wav, t)[0].cpu()
         assert m.engine.fallbacks == 0
+        if acc == "auto":               # the C-ABI option behind the keyword takes 1 or 2 only
+            with pytest.raises(ValueError):
+                m.engine.set_option("blocked_accumulation", 3)
         del m
     assert torch.equal(out["auto"], out["blocked"])
     assert not torch.equal(out["single_chain"], out["blocked"])
