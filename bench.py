@@ -271,7 +271,12 @@ def main():
     ap.add_argument("--no-cold-start", action="store_true", help="skip the time-to-first-roll subprocesses (configs 1 and 2)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the extra bf16x3 split-precision measurement")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="PLUMBING TEST of the N > 1 path on a 1-GPU box: all ranks bind device 0 over a gloo group with one "
+                         "launch per phase (no persistent kernels); the line carries dist.share_gpu = true and is no measurement")
     args = ap.parse_args()
+    if args.share_gpu:
+        os.environ["DR_BENCH_SHARE_GPU"] = "1"
 
     from diffroll_amd import launch
     if args.gpus < 1:
@@ -284,6 +289,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the engine has no CPU fallback)")
+    if launch.share_gpu():
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
@@ -291,6 +298,7 @@ def main():
     # host-side torch ops here are tiny; keep N ranks from each spawning one CPU thread per hardware thread
     torch.set_num_threads(min(16, torch.get_num_threads()))
     dist = launch.init_process_group(device, force_single=args.dist)
+    cdev = launch.collective_device(dist, device)
 
     from diffroll_amd.distributed import gather_rolls
 
@@ -307,6 +315,10 @@ def main():
     wav = (0.1 * torch.randn(B, Ls, generator=g)).to(device)
     x_T = torch.randn(B, 1, T, 88, generator=g).to(device)
     model.engine   # create + commit (weight packing / upload) outside the timed region
+    if launch.share_gpu():
+        # several processes time-share the one device: persistent kernels assume all their workgroups resident
+        model.engine.set_option("fused_stack", 0)
+        model.engine.set_option("fused_tail", 0)
 
     def one_step():
         model._fe_key = None                                   # front-end is part of every sample
@@ -329,7 +341,7 @@ def main():
             o = one_step()
         sync()
         dt_ = time.perf_counter() - t0
-        tt = torch.tensor([dt_], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt_], device=cdev, dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), o
@@ -366,7 +378,7 @@ def main():
     for _ in range(args.steps):
         one_step()
     torch.cuda.synchronize()
-    mine = torch.tensor([1e3 * (time.perf_counter() - t0) / args.steps], device=device, dtype=torch.float64)
+    mine = torch.tensor([1e3 * (time.perf_counter() - t0) / args.steps], device=cdev, dtype=torch.float64)
     if dist is not None:
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -469,11 +481,16 @@ def main():
         result["cpu_baseline"] = cpu_baseline(model, cfg, hp)
     if rank == 0 and world == 1 and not args.no_cold_start:
         result["cold_start"] = cold_start()
+    seen = result["dist"]["ranks_seen"]
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if seen != args.gpus or len(per_rank) != args.gpus:
+        # a job that ran with fewer ranks than it was asked for must not pass for a scaling point
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but the process group had {seen} rank(s) "
+                         f"({len(per_rank)} per-rank times)")
 
 
 if __name__ == "__main__":

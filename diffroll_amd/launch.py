@@ -36,11 +36,20 @@ def visible_gpus() -> int:
     return torch.cuda.device_count() if torch.cuda.is_available() else 0
 
 
+def share_gpu() -> bool:
+    """Plumbing-test mode (bench.py --share-gpu / DR_BENCH_SHARE_GPU=1): every rank binds device 0 and the process
+    group is gloo (RCCL cannot put two ranks on one device).  No hardware claim follows from such a run - it exists
+    so that the N > 1 code path (spawn -> rendezvous -> barrier -> timed loop -> all_reduce -> gathers -> JSON line)
+    executes before an 8-GPU node is available."""
+    return os.environ.get("DR_BENCH_SHARE_GPU", "0") not in ("", "0")
+
+
 def spawn_ranks(n: int, script: str, argv: List[str], port: Optional[int] = None, module: bool = False) -> int:
     """Run ``script argv`` (module=True: ``-m script argv``) as n local ranks under torch.distributed.run and return
-    its exit code.  Fails with a device-count message (not a launcher hint) when fewer than n GPUs are visible."""
+    its exit code.  Fails with a device-count message (not a launcher hint) when fewer than n GPUs are visible
+    (share_gpu(): one device is enough)."""
     have = visible_gpus()
-    if have < n:
+    if have < (1 if share_gpu() else n):
         raise SystemExit(f"{os.path.basename(script)}: {n} GPUs requested but only {have} HIP device(s) visible "
                          f"on this node")
     env = dict(os.environ)
@@ -56,7 +65,7 @@ def spawn_ranks(n: int, script: str, argv: List[str], port: Optional[int] = None
 
 def init_process_group(device, force_single: bool = False):
     """Join (or, with force_single, create a 1-rank) RCCL process group; returns the torch.distributed module or
-    None when the process is a plain single-GPU run."""
+    None when the process is a plain single-GPU run.  share_gpu(): a gloo group (collectives on host tensors)."""
     rank, world, _ = rank_env()
     if not under_launcher() and not force_single:
         return None
@@ -65,8 +74,17 @@ def init_process_group(device, force_single: bool = False):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not under_launcher():
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if share_gpu():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     return dist
+
+
+def collective_device(dist, device):
+    """Where the small tensors of host-side collectives (timings) live: the GPU under RCCL, the host under gloo."""
+    import torch
+    return device if dist is not None and dist.get_backend() == "nccl" else torch.device("cpu")
 
 
 def dist_info(dist) -> dict:
@@ -81,5 +99,8 @@ def dist_info(dist) -> dict:
         ver = f"unavailable ({type(e).__name__})"
     launcher = "torch.distributed.run (self-spawned by --gpus)" if os.environ.get("DR_SELF_SPAWNED") else (
         "torch.distributed.run" if under_launcher() else "single process, 1-rank group")
-    return {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
+    info = {"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
             "launcher": launcher}
+    if share_gpu():
+        info["share_gpu"] = True          # all ranks on device 0: a plumbing run, not a scaling point
+    return info

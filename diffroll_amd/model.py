@@ -574,10 +574,14 @@ class ClassifierFreeDiffRoll(nn.Module):
                                 float(self.hparams.generation_filter), clean_prefix)
 
     def sampling(self, batch, batch_idx=0):
-        """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec)."""
+        """task/diffusion.py:765-790 with x_T drawn on the device; returns (roll, spec).  Two optional batch entries
+        (an extension; the reference draws both from torch's global generator, :775 and :967) make a run repeatable
+        against the reference on identical inputs: 'x_T' (B, 1, T, 88) and 'noise' (timesteps, B, 1, T, 88)."""
         if self.hparams.debug:
             raise NotImplementedError("debug=True feeds the label roll where the waveform belongs "
                                       "(task/diffusion.py:780-781): a development switch of the reference, not a mode")
         frame = batch["frame"]
-        x_T = torch.randn(frame.shape[0], 1, frame.shape[1], frame.shape[2], device=self.engine.device)
-        return self.sample(x_T, batch["audio"], seed=batch_idx)
+        x_T = batch.get("x_T")
+        if x_T is None:
+            x_T = torch.randn(frame.shape[0], 1, frame.shape[1], frame.shape[2], device=self.engine.device)
+        return self.sample(x_T, batch["audio"], noise=batch.get("noise"), seed=batch_idx)

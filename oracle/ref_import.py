@@ -121,6 +121,15 @@ def _install_stubs():
             assert center and normalized and pad_mode == "reflect"
             self.hp = dict(sample_rate=sample_rate, n_fft=n_fft, hop_length=hop_length,
                            n_mels=n_mels, f_min=f_min, f_max=f_max)
+            # torchaudio 0.11 keeps its two tables as persistent buffers of two child modules, so a Lightning
+            # checkpoint of the reference carries `mel_layer.spectrogram.window` / `mel_layer.mel_scale.fb`:
+            # same names, same values here (forward below evaluates the same expressions itself)
+            self.spectrogram = nn.Module()
+            self.spectrogram.register_buffer("window", torch.hann_window(n_fft))
+            self.mel_scale = nn.Module()
+            self.mel_scale.register_buffer("fb", R.melscale_fbanks_htk(
+                n_fft // 2 + 1, float(f_min), float(f_max if f_max is not None else sample_rate // 2),
+                int(n_mels), int(sample_rate)))
 
         def forward(self, waveform):
             return R.mel_spectrogram(waveform, self.hp)
@@ -143,7 +152,7 @@ def import_reference_model():
     return ref_model
 
 
-def build_reference(hp: dict, sampler: str, w: float = 0.0, inpainting_t=None, inpainting_f=None):
+def build_reference(hp: dict, sampler: str, w: float = 0.0, inpainting_t=None, inpainting_f=None, lr: float = 1e-4):
     """Construct the reference ClassifierFreeDiffRoll (eval mode) from an oracle-style hp dict."""
     ref_model = import_reference_model()
     spec_args = to_attr(dict(sample_rate=hp["sample_rate"], n_fft=hp["n_fft"],
@@ -157,7 +166,7 @@ def build_reference(hp: dict, sampler: str, w: float = 0.0, inpainting_t=None, i
             dilation_base=hp["dilation_base"], dilation_bound=hp["dilation_bound"],
             spec_args=spec_args, spec_dropout=0.1, inpainting_t=inpainting_t,
             inpainting_f=inpainting_f,
-            lr=1e-4, timesteps=hp["timesteps"], loss_type="l2", loss_keys=["diffusion_loss"],
+            lr=lr, timesteps=hp["timesteps"], loss_type="l2", loss_keys=["diffusion_loss"],
             beta_start=hp["beta_start"], beta_end=hp["beta_end"], frame_threshold=0.5,
             training=to_attr({"mode": "x_0"}), sampling=to_attr({"type": sampler, "w": w}),
             debug=False, generation_filter=0.02)

@@ -296,6 +296,172 @@ def gen_qsample():
     save("qsample", x0=x0, noise=noise, eps=eps, t=t, sac=sac, s1m=s1m, xt=xt, x0_back=x0_back)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Trained regime: a small reference network TRAINED BY THE REFERENCE'S OWN step() on a seeded
+# synthetic transcription task, saved as a Lightning-shaped checkpoint, and the reference's 200-step rolls on it.
+# ---------------------------------------------------------------------------------------------------------------
+TRAINED_CKPT = os.path.join(OUT, "trained_small.ckpt")
+TRAINED_HP = dict(C=64, L=4, k=9, S=200, iters=4000, lr=1e-3, batch=16, clips=256, T=64)
+
+
+def synth_clips(n, T, seed, hop=512, sr=16000):
+    """Seeded synthetic transcription data: every clip is a sum of 2-6 decaying notes, each a sum of harmonic
+    partials (amplitude 1/h) of the key's fundamental; the label is the 88-key roll of the sounding frames."""
+    rng = np.random.default_rng(seed)
+    wav = np.zeros((n, T * hop), np.float64)
+    roll = np.zeros((n, T, 88), np.float32)
+    for i in range(n):
+        for _ in range(int(rng.integers(2, 7))):
+            p = int(rng.integers(15, 80))
+            on = int(rng.integers(0, T - 4))
+            off = min(T, on + int(rng.integers(4, 24)))
+            f0 = 440.0 * 2.0 ** ((21 + p - 69) / 12.0)
+            tt = np.arange((off - on) * hop) / sr
+            env = np.exp(-2.0 * tt) * np.minimum(1.0, tt / 0.005)
+            s = sum(np.sin(2 * np.pi * h * f0 * tt) / h for h in range(1, 7) if h * f0 < 7600)
+            wav[i, on * hop: off * hop] += 0.1 * float(rng.uniform(0.5, 1.0)) * env * s
+            roll[i, on:off, p] = 1.0
+    return torch.from_numpy(wav.astype(np.float32)), torch.from_numpy(roll)
+
+
+def plain(obj):
+    """hparams as plain dict / list / scalars (what the checkpoint stores)."""
+    if isinstance(obj, dict):
+        return {k: plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [plain(v) for v in obj]
+    return obj
+
+
+def train_small():
+    """Adam (the reference's configure_optimizers, task/diffusion.py:1057-1067) on the reference's own step()
+    (:651-763: q_sample at a random t per sample, forward in train mode with spec_dropout=0.1, mode 'x_0',
+    p_losses 'l2') until the loss has left the random regime (0.015 -> ~0.001); writes the checkpoint as
+    {'state_dict', 'hyper_parameters', ...} - the entries Lightning 1.6.4 writes that load_from_checkpoint reads,
+    hyper-parameter containers as plain dicts (omegaconf is absent here)."""
+    cfg = TRAINED_HP
+    hp = hp_small(cfg["k"], C=cfg["C"], L=cfg["L"], S=cfg["S"])
+    torch.manual_seed(1234)
+    m = RI.build_reference(hp, "cfdg_ddpm_x0", 0.5, lr=cfg["lr"])
+    wav, roll = synth_clips(cfg["clips"], cfg["T"], seed=0)
+    m.train()
+    opt = m.configure_optimizers()[0]
+    g = torch.Generator().manual_seed(5)
+    curve = []
+    for it in range(cfg["iters"]):
+        idx = torch.randint(0, cfg["clips"], (cfg["batch"],), generator=g)
+        losses, _ = m.step({"frame": roll[idx], "audio": wav[idx]})
+        loss = losses["diffusion_loss"]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        curve.append(float(loss.detach()))
+        if it % 500 == 0:
+            print(f"  train it {it:5d}  loss {np.mean(curve[-100:]):.5f}", flush=True)
+    m.eval()
+    torch.save({"epoch": 0, "global_step": cfg["iters"], "pytorch-lightning_version": "1.6.4",
+                "state_dict": m.state_dict(), "hyper_parameters": plain(dict(m.hparams)),
+                "loss_curve": [float(np.mean(curve[i:i + 100])) for i in range(0, len(curve), 100)]}, TRAINED_CKPT)
+    print(f"trained_small.ckpt  {os.path.getsize(TRAINED_CKPT) / 1024:.1f} kB   loss {np.mean(curve[:100]):.5f} -> {np.mean(curve[-100:]):.5f}")
+
+
+def reference_from_ckpt(ckpt, sampler, w, inpainting_t=None):
+    """The reference class constructed from the checkpoint's hyper-parameters + its state_dict, as
+    LightningModule.load_from_checkpoint(path, sampling=..., inpainting_t=...) does (sampling.py:54-65)."""
+    ref_model = RI.import_reference_model()
+    kw = RI.to_attr(dict(ckpt["hyper_parameters"]))
+    kw["sampling"] = RI.to_attr({"type": sampler, "w": w})
+    kw["inpainting_t"] = inpainting_t
+    import contextlib
+    import io
+    with contextlib.redirect_stderr(io.StringIO()):
+        m = ref_model.ClassifierFreeDiffRoll(**kw)
+    m.load_state_dict(ckpt["state_dict"])
+    m.eval()
+    return m
+
+
+def seeded_noise(seed, S, B, T):
+    g = torch.Generator().manual_seed(seed)
+    x_T = torch.randn(B, 1, T, 88, generator=g)
+    noise = torch.randn(S, B, 1, T, 88, generator=g)
+    return x_T, noise
+
+
+def bit_checksum(t):
+    """Exact, order-independent checksums of an fp32 tensor: int64 sums of its bit patterns (whole and >> 9)."""
+    b = t.contiguous().view(torch.int32).to(torch.int64)
+    return np.array([int(b.sum()), int((b >> 9).sum())], dtype=np.int64)
+
+
+def gen_trained():
+    """The reference's own rolls on the trained checkpoint: 200-step cfdg_ddpm_x0 (w = 0.5) through its
+    test_step (task/diffusion.py:312-428, batch_idx = 1: no figures) with the logged Frame_F1, generation_ddpm_x0
+    and inpainting_ddpm_x0 chains, and single evaluations.  The (S, B, 1, T, 88) noise is 18 MB: the fixture
+    stores its SEED (torch CPU generator) and checksums, the tests regenerate it and check the checksums."""
+    from sklearn.metrics import confusion_matrix, precision_recall_fscore_support
+    if not os.path.exists(TRAINED_CKPT) or "--retrain" in sys.argv:
+        train_small()
+    ckpt = torch.load(TRAINED_CKPT, map_location="cpu", weights_only=False)
+    S = int(ckpt["hyper_parameters"]["timesteps"])
+    B, T = 4, 64
+    wav, label = synth_clips(B, T, seed=99)                  # clips the training set does not contain
+    noise_seed = 20260929
+    x_T, noise = seeded_noise(noise_seed, S, B, T)
+    out = dict(hp=json.dumps({k: v for k, v in ckpt["hyper_parameters"].items()
+                              if k in ("residual_channels", "residual_layers", "kernel_size", "dilation_base",
+                                       "dilation_bound", "n_mels", "timesteps", "beta_start", "beta_end")}
+                             | {k: ckpt["hyper_parameters"]["spec_args"][k]
+                                for k in ("sample_rate", "n_fft", "hop_length", "f_min", "f_max")}),
+               wav=wav, label=label, noise_seed=noise_seed, w=0.5, inpainting_t=np.array([16, 32]),
+               x_T_bits=bit_checksum(x_T), noise_bits=bit_checksum(noise), noise_last=noise[S - 1], wsum=weight_checksum({k: v for k, v in ckpt["state_dict"].items()
+                                                              if not k.startswith("mel_layer")}))
+    # --- transcription: the reference's test_step
+    m = reference_from_ckpt(ckpt, "cfdg_ddpm_x0", 0.5)
+    logged = {}
+    m.log = lambda key, value, *a, **k: logged.__setitem__(key, float(value))
+    kept = {}
+    orig_sampling = m.sampling
+
+    def sampling_keep(batch, batch_idx):
+        noise_list, spec = orig_sampling(batch, batch_idx)
+        kept["roll"], kept["spec"] = noise_list[-1][0], spec
+        return noise_list, spec
+    m.sampling = sampling_keep
+    with torch.no_grad(), RI.injected_noise([x_T] + [noise[t] for t in reversed(range(1, S))]):
+        m.test_step({"frame": label, "audio": wav}, 1)
+    roll = torch.from_numpy(np.asarray(kept["roll"]))
+    thr = float(m.hparams.frame_threshold)
+    pred = roll.flatten().numpy() > thr
+    p_, r_, f_, _ = precision_recall_fscore_support(label.unsqueeze(1).flatten().numpy(), pred, average="binary")
+    assert abs(f_ - logged["Test/Frame_F1"]) < 1e-12
+    tn, fp, fn, tp = confusion_matrix(label.flatten().numpy() > 0.5, pred).ravel()
+    out.update(cfdg_roll=roll, cfdg_spec=kept["spec"], frame_threshold=thr, frame_f1=logged["Test/Frame_F1"],
+               frame_p=p_, frame_r=r_, tp=int(tp), fp=int(fp), fn=int(fn),
+               cfdg_margin=float((roll - thr).abs().min()))
+    print(f"  cfdg_ddpm_x0: Frame_F1 {f_:.4f} (tp {tp} fp {fp} fn {fn}), roll in [{float(roll.min()):.3f}, {float(roll.max()):.3f}], "
+          f"closest value to the threshold {out['cfdg_margin']:.2e}")
+    # --- generation / inpainting chains (loop of task/diffusion.py:528-534)
+    for sampler, it in (("generation_ddpm_x0", None), ("inpainting_ddpm_x0", [16, 32])):
+        m = reference_from_ckpt(ckpt, sampler, 0.5, inpainting_t=it)
+        xx = x_T
+        with torch.no_grad(), RI.injected_noise([noise[t] for t in reversed(range(1, S))]):
+            for t_index in reversed(range(S)):
+                xx, _ = m.reverse_diffusion(xx, wav, t_index)
+        out[f"{sampler}_roll"] = xx
+        out[f"{sampler}_margin"] = float((xx - thr).abs().min())
+        print(f"  {sampler}: roll in [{float(xx.min()):.3f}, {float(xx.max()):.3f}], {int((xx > thr).sum())} frames on")
+    # --- single evaluations + how saturated the gates are (the regime the fixture is for)
+    m = reference_from_ckpt(ckpt, "cfdg_ddpm_x0", 0.5)
+    with torch.no_grad():
+        for t in (199, 100, 0):
+            tt = torch.tensor(t).repeat(B)
+            xq = x_T if t == 199 else noise[t]
+            out[f"x0_c_t{t}"], _ = m(xq, wav, tt)
+            out[f"x0_u_t{t}"], _ = m(xq, torch.zeros_like(wav), tt, sampling=True)
+    save("trained_small", **out)
+
+
 if __name__ == "__main__":
     assert RI.reference_available(), "needs /root/reference"
     torch.set_num_threads(8)
@@ -320,6 +486,9 @@ if __name__ == "__main__":
     if "--framewise-only" in sys.argv:
         gen_framewise()
         sys.exit(0)
+    if "--trained-only" in sys.argv:
+        gen_trained()
+        sys.exit(0)
     gen_schedule()
     gen_frontend()
     gen_forward()
@@ -331,3 +500,4 @@ if __name__ == "__main__":
     gen_trainable_spec()
     gen_forward_steps()
     gen_framewise()
+    gen_trained()

@@ -223,3 +223,60 @@ def test_two_processes_share_the_gpu_and_gather(tmp_path):
         whole = sample_sharded(m, x, wav, seed=3 + rep).cpu()
         d = float((got[rep] - whole).abs().max())
         assert d <= ATOL_SHARD, (rep, d)
+
+
+def _clean_env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "DR_BENCH_SHARE_GPU", "DR_SELF_SPAWNED"):
+        env.pop(k, None)
+    return env
+
+
+def test_two_rank_bench_path_executes_on_one_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the N > 1 benchmark path - launch.spawn_ranks ->
+    torch.distributed.run -> init_process_group -> barrier -> timed loop -> all_reduce(MAX) -> per-rank all_gather ->
+    gather_rolls -> the JSON line - with both ranks on the one leased device over gloo.  No hardware claim follows from
+    it; it guarantees that the real 8-GPU run does not die in plumbing."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--config", "1",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-split", "--no-roofline", "--no-cold-start"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dist"]["ranks_seen"] == 2 and j["dist"]["backend"] == "gloo" and j["dist"]["share_gpu"] is True
+    assert len(j["per_rank_ms_per_step"]["all"]) == 2 and min(j["per_rank_ms_per_step"]["all"]) > 0
+    assert j["scaling"] == "weak" and j["steps"] == 2 and j["config"]["parallelism"] == "batch-shard x2"
+    # value = BOTH ranks' frames over the max-over-ranks time
+    assert abs(j["value"] - 2 * 1 * 125 * 1e3 / j["ms_per_step"]) <= 0.01 * j["value"]
+    assert j["gather_us"] > 0
+
+
+def test_scale_table_emits_a_scale_record_for_one_and_two_ranks(tmp_path):
+    """tools/scale_table.py --gpus 1,2 --share-gpu --scale-json: the SCALE-shaped record the 8-GPU day will produce,
+    from a 1-rank run and a 2-rank run that really had two ranks (ranks_seen checked per cell; exit code 0)."""
+    import json
+    out = str(tmp_path / "scale.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_table.py"), "--gpus", "1,2", "--configs", "1",
+                        "--steps", "2", "--warmup", "1", "--share-gpu", "--scale-json", out],
+                       env=_clean_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    rec = json.load(open(out))
+    assert rec["ok"] is True and rec["problems"] == []
+    rows = rec["configs"]["1"]
+    assert [row["n_gpus"] for row in rows] == [1, 2] and [row["ranks_seen"] for row in rows] == [1, 2]
+    assert rows[0]["share_gpu"] is False and rows[1]["share_gpu"] is True and len(rows[1]["per_rank_ms_all"]) == 2
+    assert rows[1]["efficiency_vs_n1"] is not None and rows[1]["value"] > 0
+
+
+def test_bench_exits_non_zero_when_the_group_is_smaller_than_asked():
+    """One rank started by hand with WORLD_SIZE=1 but --gpus 2: refused, no JSON line."""
+    env = _clean_env()
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+    from diffroll_amd.launch import free_port
+    env["MASTER_PORT"] = str(free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--config", "1"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and '"metric"' not in r.stdout

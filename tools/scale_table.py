@@ -27,9 +27,11 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_cell(n, cfg, steps, warmup, timeout):
+def run_cell(n, cfg, steps, warmup, timeout, share_gpu=False):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", str(cfg), "--steps", str(steps),
            "--warmup", str(warmup), "--no-split", "--no-cpu-baseline", "--no-roofline", "--no-cold-start"]
+    if share_gpu and n > 1:
+        cmd.append("--share-gpu")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["NCCL_DEBUG"] = env.get("NCCL_DEBUG", "VERSION")           # RCCL prints its own version banner once per job
@@ -74,6 +76,7 @@ def scale_record(table, gpus, configs):
                          "per_rank_ms_min": pr.get("min"), "per_rank_ms_max": pr.get("max"), "gather_us": j.get("gather_us"),
                          "ranks_seen": seen, "backend": d.get("backend"), "rccl_version": d.get("rccl_version"),
                          "rccl_banner": j.get("_rccl_banner"), "launcher": d.get("launcher"), "scaling": j.get("scaling"),
+                         "share_gpu": bool(d.get("share_gpu", False)), "per_rank_ms_all": pr.get("all"),
                          "efficiency_vs_n1": (j["value"] / (n * base)) if base else None, "wall_s": j["_wall_s"],
                          "workload": j.get("config", {}).get("workload")})
         rec["configs"][str(c)] = rows
@@ -89,6 +92,9 @@ def main():
     ap.add_argument("--timeout", type=int, default=1200)
     ap.add_argument("--out", default=None)
     ap.add_argument("--scale-json", default=None)
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="plumbing test on a 1-GPU box: cells with N > 1 run `bench.py --share-gpu` (all ranks on device 0, "
+                         "gloo, no persistent kernels) - the record marks them; their values are no scaling points")
     args = ap.parse_args()
     gpus = [int(v) for v in args.gpus.split(",")]
     configs = [int(v) for v in args.configs.split(",")]
@@ -98,7 +104,7 @@ def main():
     for c in configs:
         base = None
         for n in gpus:
-            j = run_cell(n, c, args.steps, args.warmup, args.timeout)
+            j = run_cell(n, c, args.steps, args.warmup, args.timeout, args.share_gpu)
             table[f"config{c}/gpus{n}"] = j
             if "error" in j:
                 print(f"{c:>6} {n:>4} {'-':>10} {'-':>9} {'-':>9} {'-':>9} {'-':>9} {'-':>8} {'-':>6}  {j['error']}")
