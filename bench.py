@@ -228,6 +228,14 @@ def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
             t0 = time.perf_counter()
             R.reverse_step(params, hp, sch, sampler, x[:1], spec[:1], S - 1, z[:1], W_CFG, table)
             t_one = time.perf_counter() - t0
+            # ... and the N = all figure (every hardware thread the box reports): the same one-clip step (the whole batch at
+            # 256 threads inside this container's CPU quota took 118 s per step when it was tried - the sweep above exists
+            # because of that), scaled to the batch like the single-thread figure
+            n_all = os.cpu_count() or default_threads
+            torch.set_num_threads(n_all)
+            t0 = time.perf_counter()
+            R.reverse_step(params, hp, sch, sampler, x[:1], spec[:1], S - 1, z[:1], W_CFG, table)
+            t_all = time.perf_counter() - t0
         finally:
             torch.set_num_threads(default_threads)
     per_step = t_steps / n
@@ -249,6 +257,9 @@ def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
         "threads_note": f"thread count chosen by a short ascending sweep over 4..128 (os.cpu_count() = {os.cpu_count()})",
         "single_thread": {"value": round(T / (t_one * S), 3), "unit": "frames/s", "cores": 1,
                           "sample": f"1 reverse step of 1 clip ({t_one:.1f} s), extrapolated to {S} steps"},
+        "all_threads": {"value": round(T / (t_all * S), 3), "unit": "frames/s", "cores": n_all,
+                        "sample": f"1 reverse step of 1 clip ({t_all:.1f} s) with torch.set_num_threads(os.cpu_count() = {n_all}), "
+                                  f"extrapolated to {S} steps (BASELINE.md section 3: N = all)"},
     }
 
 

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 8
+DR_ABI_VERSION = 9
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME, DR_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 
 SAMPLERS = {
@@ -38,7 +38,7 @@ EXPORTS = [
     "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
     "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
     "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds", "dr_tail_launches",
-    "dr_pending_timeout", "dr_cold_times",
+    "dr_pending_timeout", "dr_cold_times", "dr_debug_tenants",
 ]
 
 
@@ -127,6 +127,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_debug_stft_power.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp]
     lib.dr_debug_bounds.restype = C.c_int
     lib.dr_debug_bounds.argtypes = [C.POINTER(C.c_int64), C.c_int]
+    lib.dr_debug_tenants.restype = C.c_int
+    lib.dr_debug_tenants.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     lib.dr_set_spec_norm.restype = C.c_int
     lib.dr_set_spec_norm.argtypes = [vp, C.c_int]
     lib.dr_set_precision.restype = C.c_int

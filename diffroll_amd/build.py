@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffroll_amd.so")
 # one translation unit per kernel family (a kernel edit rebuilds its unit only; the units compile in parallel)
-SOURCES = ["gemm.hip", "stack.hip", "tail.hip", "update.hip", "frontend.hip", "engine.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "device_common.h", "gemm_body.h", "persistent.h", "update_quad.h")] + \
+SOURCES = ["gemm.hip", "stack.hip", "tail.hip", "update.hip", "frontend.hip", "pack.hip", "plan.hip", "abi.hip", "debug_abi.hip", "comm.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "device_common.h", "gemm_body.h", "persistent.h", "update_quad.h", "engine_state.h")] + \
           [os.path.join(os.path.dirname(HERE), "include", "diffroll_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--json", action="store_true")
     ap.add_argument("--steady", type=int, default=3)
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="dr_set_option applied right after dr_create (e.g. tune.pack_threads=1, tune.s3_eager=1: the 'before' "
+                         "of the cold-start report)")
     args = ap.parse_args()
     out = {"config": args.config}
     out["interpreter_s"] = (proc_age_s() or 0.0) - (time.perf_counter() - T0) if proc_age_s() is not None else None
@@ -67,6 +70,9 @@ def main():
         t0 = time.perf_counter()
         orig_init(self, *a, **k)
         marks["create_s"] = time.perf_counter() - t0
+        for item in args.tune:
+            name, value = item.split("=", 1)
+            self.set_option(name, int(value))
 
     def timed_load(self, params):
         t0 = time.perf_counter()

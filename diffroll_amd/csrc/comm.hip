@@ -127,17 +127,21 @@ int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank) {
 
 int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, int B_local, int T, void* stream) {
     if (!comm || !d_shard || !d_full) return cfail(DR_EINVAL, "null argument");
-    // the one piece of engine state that matters here: a roll produced by a fused launch that timed out must not be
-    // gathered (include/diffroll_amd.h: dr_finish); `e` may be NULL
-    if (e && dr_pending_timeout(e, stream) != DR_OK) return cfail(DR_ETIMEOUT, dr_last_error(e));
     if (B_local < 0 || T <= 0) return cfail(DR_EINVAL, "bad shape");
     if (B_local == 0) return DR_OK;
+    // The one piece of engine state that matters here: a roll produced by a fused launch that timed out is invalid
+    // (include/diffroll_amd.h: dr_finish).  A time-out is a PER-RANK event and the gather is collective: a rank that
+    // returned before the collective would leave its peers blocked in ncclAllGather for ever.  So this rank still takes
+    // part (its shard is garbage, the peers' shards are not), and reports DR_ETIMEOUT afterwards: the caller recomputes
+    // its shard and gathers again - all ranks, since they all received the invalid shard.  `e` may be NULL.
+    const bool invalid = e && dr_pending_timeout(e, stream) != DR_OK;
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != comm->device && hipSetDevice(comm->device) != hipSuccess) return cfail(DR_EHIP, "hipSetDevice failed");
     int rc = rccl().AllGather(d_shard, d_full, (size_t)B_local * T * 88, kFloat32, comm->comm, (hipStream_t)stream);
     if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev);
-    return rc ? cfail(DR_EHIP, nccl_err("ncclAllGather", rc)) : DR_OK;
+    if (rc) return cfail(DR_EHIP, nccl_err("ncclAllGather", rc));
+    return invalid ? cfail(DR_ETIMEOUT, dr_last_error(e)) : DR_OK;
 }
 
 }  // extern "C"

@@ -21,6 +21,8 @@
 
 namespace dr {
 
+Tuning& tuning() { static Tuning t; return t; }
+
 DR_BOUNDS_TU(gemm)
 hipError_t read_bounds(unsigned long long* out4) {
     unsigned long long t[4];
@@ -246,10 +248,8 @@ hipError_t launch_pointwise_ksplit(const GemmArgs& a, int NW, hipStream_t s) {
 // for 5-round launches of big convs - 640-frame generation batches - and paid 13.9x the algorithmic traffic.)
 static int pick_xcd_mapping(int MT, int NT, double wbytes, double xbytes) {
     if (MT <= 1 || NT % 8 != 0) return 0;
-    static const int force = getenv("DR_XCD_N") ? atoi(getenv("DR_XCD_N")) : -1;      // tuning experiments
-    if (force >= 0) return force;
-    static const int model = getenv("DR_XCD_MODEL") ? atoi(getenv("DR_XCD_MODEL")) : 1;
-    if (!model) return xbytes > wbytes ? 1 : 0;
+    if (tuning().xcd_n >= 0) return tuning().xcd_n;      // A/B experiments
+    if (!tuning().xcd_model) return xbytes > wbytes ? 1 : 0;
     const double l2 = 4.0 * 1024 * 1024, cus_per_xcd = 32.0;
     const double conc = cus_per_xcd / MT < 1.0 ? 1.0 : cus_per_xcd / MT;               // frame tiles resident per XCD (mapping 1)
     const double rounds1 = wbytes <= l2 ? 1.0 : ((NT / 8.0) / conc < 1.0 ? 1.0 : (NT / 8.0) / conc);
@@ -346,9 +346,8 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
 }
 
 KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n) {
-    static const int ks_max = getenv("DR_KSPLIT_MAX") ? atoi(getenv("DR_KSPLIT_MAX")) : 16;   // tuning experiments
-    static const long max_blocks_env = getenv("DR_KSPLIT_BLOCKS") ? atol(getenv("DR_KSPLIT_BLOCKS")) : 0;
-    const long max_blocks = max_blocks_env ? max_blocks_env : (prec ? 256 : 2048);
+    const int ks_max = tuning().ksplit_max;
+    const long max_blocks = tuning().ksplit_blocks ? tuning().ksplit_blocks : (prec ? 256 : 2048);
     const int BN = gemm_block_frames(NI);
     const double t_full = (double)kchunks * taps * 16.0 * (BN / 32) * 69.0 / 2400.0;
     auto cost = [&](int ks) {
@@ -388,6 +387,12 @@ static hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     if constexpr (NI == 2 && KS == 1 && EPI == EPI_GATE) {
         if (a.fold128) {
             hipLaunchKernelGGL((gemm_kernel<2, 1, EPI_GATE, PREC, 1>), grid, dim3(512), lds, s, b);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (NI == 1 && KS == 1 && EPI == EPI_GATE && PREC == 0) {
+        if (a.nofold64 && b.ksplit == 1) {    // (see GemmArgs::nofold64)
+            hipLaunchKernelGGL((gemm_kernel<1, 1, EPI_GATE, 0, 0>), grid, dim3(512), lds, s, b);
             return hipGetLastError();
         }
     }
@@ -432,6 +437,7 @@ hipError_t init_kernels() {
     if ((e = init_gemm_t<1, 4, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = init_gemm_t<1, 1, EPI_RES_SKIP, 1>()) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<1, 1, EPI_GATE, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<2, 1, EPI_GATE, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<5, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<3, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -467,7 +473,7 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, int NI, hipStream_t s, int pr
     // EPI_RES_SKIP also keeps its read-modify-write tile in LDS, which leaves room for 64 channels at NI = 2
     int KS = a.taps != 1 ? 1 : (a.kchunks % 4 == 0 ? 4 : (a.kchunks % 2 == 0 ? 2 : 1));
     if (epi == EPI_RES_SKIP && NI == 2 && KS == 4) KS = 2;
-    static const int ks_force = getenv("DR_1X1_KS") ? atoi(getenv("DR_1X1_KS")) : 0;   // tuning experiments
+    const int ks_force = tuning().one_ks;
     if (ks_force && a.taps == 1 && a.kchunks % ks_force == 0) KS = ks_force;
     if (NI == 1) {
         if (KS == 4) return launch_gemm_ni<1, 4>(a, epi, s);

@@ -1,4 +1,4 @@
-// Internal launch interface between engine.hip (host logic, C-ABI) and the kernel translation units gemm / stack / tail / update / frontend .hip (gfx950 kernels).
+// Internal launch interface between the host translation units (pack / plan / abi / debug_abi .hip: host logic, C-ABI) and the kernel translation units gemm / stack / tail / update / frontend .hip (gfx950 kernels).
 // Not part of the public ABI (that is include/diffroll_amd.h).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,6 +23,28 @@ namespace dr {
 //  = W[orig_row(mtile,row)][channel = kchunk*32 + g*8 + hi*4 + i][tap]; one (mtile,kchunk,tap)
 //  slab is 16 KiB, contiguous, and is the exact LDS image the kernel reads (linear copy).
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// A/B knobs of the planners and launchers (process-wide; defaults = what ships).  They are set through
+// dr_set_option(e, "tune.<field>", value) by tools/ and tests - the library reads no environment variable.
+// ---------------------------------------------------------------------------------------------
+struct Tuning {
+    int pack_threads = 16;   // host threads packing the layers at dr_commit (1 = serial)
+    int tile = 0;            // force a conv / LDS-staged 1x1 tile: 3201 / 3202 / 3203 / 3205 (32x32 MFMA, NI) or 1603 / 1605 (16x16, NJ); 0 = cost model
+    int pw = 1;              // 1x1 residual/skip GEMM: 1 = operands direct from L2 (pw_kernel), 0 = the LDS-staged kernels
+    int pw_nw = 0;           // force 32 * pw_nw frames per pw_kernel block (2..5); 0 = cost model
+    int pwk = 1;             // under-filled 1x1 launches: K split over the block's waves (pwk_kernel)
+    int ksplit_max = 16;     // largest split-K factor of gemm_kernel launches (1 = never split)
+    long ksplit_blocks = 0;  // cap on tiles x ksplit (0 = 2048 fp32 / 256 split-bf16)
+    int one_ks = 0;          // force the 1x1 GEMMs' channels-per-hand-over (KS = 1 / 2 / 4); 0 = by divisibility
+    int stack3 = 1;          // the split-bf16 flavour of the fused residual stack
+    int stack_fl = 0;        // force the fused stack's block flavour (1 = 64-frame, 2 = 128-frame blocks); 0 = cost model
+    int xcd_n = -1;          // force the block -> XCD mapping of per-phase GEMM launches (0 / 1); -1 = traffic model
+    int xcd_model = 1;       // 0 = the rounds 1-2 rule (activation bytes > weight bytes)
+    int s3_eager = 0;        // build the split-bf16 packings at every dr_commit (rounds 1-3 behaviour)
+    int debug_chunks = 0;    // dr_debug_ticks prints the chunk-start tick marks
+};
+Tuning& tuning();            // gemm.hip
 
 enum Epilogue : int {
     EPI_PLAIN = 0,     // y = alpha*acc + bias
@@ -84,6 +106,10 @@ struct GemmArgs {
     long long* dbg;          // measurement hook: block 0 writes {main-loop ticks, block ticks} (s_memtime); null normally
     int lds_bytes;           // set by the launcher: dynamic LDS of the launch (read by DR_BOUNDS checker builds only)
     int fold128;             // EPI_GATE on 128-frame blocks (NI = 2, fp32): 1 = the blocked-accumulation instantiation
+    int nofold64;            // EPI_GATE on 64-frame blocks (NI = 1, fp32, no split-K): 1 = ONE chain per output instead of the blocked
+                             // accumulation every other 64-frame launch uses - the shared first-layer conv of an engine whose fused
+                             // 128-frame stack runs single-chain (blocked_accumulation = 1), so that the per-phase launch and the
+                             // tail kernel's copy of that conv (TailArgs::fold = 0) produce the same bits
     int wt_store;            // fused residual stack only (COH bodies): 1 = the tensors handed to other workgroups are
                              // stored write-through (sc1), 0 = plain stores (every workgroup of the group shares one
                              // XCD's L2, verified at run time)

@@ -227,8 +227,7 @@ class ClassifierFreeDiffRoll(nn.Module):
         if self._engine.precision != self.precision:
             self._engine.set_precision(self.precision)
         want = 1 if self.accumulation == "single_chain" else 2
-        env_forced = self.accumulation == "auto" and "DR_BLOCKED" in __import__("os").environ     # (A/B runs of the tools)
-        if getattr(self._engine, "_blocked", None) != want and not env_forced:
+        if getattr(self._engine, "_blocked", None) != want:
             self._engine.set_option("blocked_accumulation", want)
             self._engine._blocked = want
         return self._engine

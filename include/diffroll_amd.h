@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 8
+#define DR_ABI_VERSION 9
 
 enum {
     DR_OK = 0,
@@ -280,6 +280,10 @@ int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d
  * out4 = {code of the first violated check (0 = none), two details, number of violations} since the last reset.
  * A production build returns DR_ESTATE.  Synchronises the device. */
 int dr_debug_bounds(int64_t* out4, int reset);
+/* Test hook of the co-tenant detection (csrc/tenants.h): scans a KFD sysfs tree rooted at kfd_root (the real one is
+ * /sys/class/kfd/kfd) for the GPU at PCI (domain, bus, device): out4 = {the driver's gpu_id or -1, processes holding a
+ * compute queue on it, the sum of their cu_occupancy, 1 if the proc directory was readable}.  No engine, no GPU. */
+int dr_debug_tenants(const char* kfd_root, int pci_domain, int pci_bus, int pci_device, int64_t* out4);
 
 /* Spectrogram normalisation of the following dr_frontend calls: the mode of Normalization(0, 1, norm_args[2])
  * (model/diffwave.py:632, model/utils.py:10-32) - min-max per clip ("imagewise", the default and the released
@@ -341,6 +345,13 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          later fused launches return at once, dr_finish reports DR_ETIMEOUT and heals, and any
  *                          other call fails with DR_ETIMEOUT until dr_finish / dr_stack_status has cleared it.
  *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
+ *   "tune.<field>"         A/B knobs of the tile / split-K / fused-stack planners and the launchers, PROCESS-wide (they
+ *                          apply to every engine of the process from the next launch on): tune.tile (3201 / 3202 / 3203 /
+ *                          3205 / 1603 / 1605 = MFMA size and frame tiles per wave; 0 = cost model), tune.pw, tune.pw_nw,
+ *                          tune.pwk, tune.ksplit_max, tune.ksplit_blocks, tune.one_ks, tune.stack3, tune.stack_fl,
+ *                          tune.xcd_n, tune.xcd_model, tune.pack_threads, tune.s3_eager, tune.debug_chunks - fields and
+ *                          defaults: csrc/kernels.h `Tuning`.  What tools/ and the bit-identity tests pin kernel flavours
+ *                          with (tools/tuning_env.py); the library reads NO environment variable.
  */
 int dr_set_option(dr_engine* e, const char* name, int value);
 /* Synchronises the device.  *timed_out != 0: a group barrier of the fused kernel ran into its spin bound (results

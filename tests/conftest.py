@@ -19,6 +19,8 @@ def pytest_configure(config):
     # 16 for these shapes (bench.py cpu_baseline measures it) - cap it so the parity suite spends its time on the GPU
     import torch
     torch.set_num_threads(min(16, torch.get_num_threads()))
+    from tools import tuning_env          # DR_TEST_TUNE="fused_stack=0,...": a forced-mode run of the suite
+    tuning_env.install()
 
 
 @pytest.fixture(scope="session")

@@ -1,5 +1,5 @@
 """Child process of tests/test_gpu_fused.py: runs every case of one block flavour with the per-phase kernels
-pinned (by the tuning overrides, which are read once per process) to the SAME kernel flavours the fused kernel
+pinned (by the tune.* options the parent passes in DR_TEST_TUNE, tools/tuning_env.py) to the SAME kernel flavours the fused kernel
 is built from - 32x32 MFMA conv tiles of that width, no split-K, the direct-from-L2 1x1 - so that fused and
 per-phase results must agree bit for bit.  Prints one JSON line."""
 import json
@@ -14,6 +14,9 @@ import torch  # noqa: E402
 
 from oracle import diffroll_ref as R  # noqa: E402
 from test_gpu_parity import make_model  # noqa: E402
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # the parent pins the kernel flavours of this process (DR_TEST_TUNE)
 
 CASES = {
     1: [  # C, layers, k, B, T, sampler            (64-frame blocks)

@@ -161,3 +161,71 @@ def test_checker_build_variants_are_declared():
     assert src.count("DR_CHECK_LDS(") >= 12 and "check_gemm_extents" in src      # the instrumentation is there
     for unit in ("gemm", "stack", "tail"):                                       # ... in every unit that carries checks
         assert f"DR_BOUNDS_TU({unit})" in src
+
+
+def test_library_reads_no_environment_variable():
+    """the A/B knobs are dr_set_option names ("tune.*", csrc/kernels.h Tuning) - the shipped library
+    neither imports getenv nor carries a DR_* string, and no source under csrc/ calls getenv."""
+    import subprocess
+    from diffroll_amd import build
+    lib = build.build(verbose=False)
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    strs = subprocess.run(["strings", lib], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert [s for s in strs if s.startswith("DR_")] == []
+    csrc = os.path.join(os.path.dirname(os.path.abspath(build.__file__)), "csrc")
+    for name in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, name)).read(), name
+
+
+def test_tuning_env_hook_parses_and_merges():
+    from tools import tuning_env
+    assert tuning_env.parse("fused_stack=0, tune.tile=3202") == {"fused_stack": 0, "tune.tile": 3202}
+    env = tuning_env.env_with({"DR_TEST_TUNE": "fused_tail=0"}, tune__stack_fl=2, blocked_accumulation=1)
+    assert tuning_env.parse(env["DR_TEST_TUNE"]) == {"fused_tail": 0, "tune.stack_fl": 2, "blocked_accumulation": 1}
+
+
+def _fake_kfd(root, procs, nodes):
+    """A /sys/class/kfd/kfd look-alike: procs = {pid: {"queues": [gpuid, ...], "occ": {gpuid: cus}}}, nodes = [(gpu_id,
+    location_id, domain)]."""
+    for i, (gid, loc, dom) in enumerate(nodes):
+        nd = os.path.join(root, "topology", "nodes", str(i))
+        os.makedirs(nd)
+        open(os.path.join(nd, "gpu_id"), "w").write(f"{gid}\n")
+        open(os.path.join(nd, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {loc}\ndomain {dom}\ndrm_render_minor 128\n")
+    for pid, p in procs.items():
+        pd = os.path.join(root, "proc", str(pid))
+        os.makedirs(os.path.join(pd, "queues"))
+        open(os.path.join(pd, "pasid"), "w").write("32770\n")
+        for n, gid in enumerate(p.get("queues", [])):
+            qd = os.path.join(pd, "queues", str(n))
+            os.makedirs(qd)
+            open(os.path.join(qd, "gpuid"), "w").write(f"{gid}\n")
+            open(os.path.join(qd, "type"), "w").write("0\n")
+        for gid, cus in p.get("occ", {}).items():
+            sd = os.path.join(pd, f"stats_{gid}")
+            os.makedirs(sd)
+            open(os.path.join(sd, "cu_occupancy"), "w").write(f"{cus}\n")
+
+
+def test_co_tenant_scan_on_a_fake_kfd_tree(tmp_path):
+    """csrc/tenants.h through dr_debug_tenants: the GPU is found by PCI address, processes are counted by the queues
+    they hold on THAT GPU (host daemons without queues and tenants of other GPUs do not count), and the busy CUs are
+    theirs.  The layout is what an MI355X node's /sys/class/kfd/kfd shows (profiles/r05_kfd_sysfs_probe.txt)."""
+    from diffroll_amd import _cabi
+    lib = _cabi.load_library()
+    root = str(tmp_path / "kfd")
+    _fake_kfd(root, procs={
+        1347236: {"queues": [28206, 28206], "occ": {28206: 0}},            # "us": queues on our GPU, idle
+        227209: {"queues": [], "occ": {28206: 0, 25266: 0}},               # a host daemon: contexts everywhere, no queue
+        1321268: {"queues": [25266, 25266, 25266], "occ": {25266: 77}},    # a busy tenant of ANOTHER GPU
+    }, nodes=[(0, 0, 0), (25266, 0x1500, 0), (28206, 0x5A00, 0)])
+    out = (C.c_int64 * 4)()
+    assert lib.dr_debug_tenants(root.encode(), 0, 0x5A, 0, out) == 0
+    assert list(out) == [28206, 1, 0, 1]                                    # our GPU: one holder, nothing busy
+    _fake_kfd(root, procs={1350000: {"queues": [28206], "occ": {28206: 133}}}, nodes=[])
+    assert lib.dr_debug_tenants(root.encode(), 0, 0x5A, 0, out) == 0
+    assert list(out) == [28206, 2, 133, 1]                                  # a second process computing on it: the engine yields
+    assert lib.dr_debug_tenants(root.encode(), 0, 0x15, 0, out) == 0 and list(out) == [25266, 1, 77, 1]
+    assert lib.dr_debug_tenants(root.encode(), 0, 0x77, 0, out) == 0 and out[0] == -1        # a GPU the tree does not list
+    assert lib.dr_debug_tenants(str(tmp_path / "absent").encode(), 0, 0x5A, 0, out) == 0 and out[0] == -1

@@ -39,7 +39,7 @@ def _run_both(m, fn, xcds=(1, 0)):
 @pytest.mark.parametrize("ni", ["1", "2", "2b", "1s", "2s", "2sb"])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
-    pinned to the flavours the fused kernel is built from (the overrides are read once per process).  "2b" = the
+    pinned to the flavours the fused kernel is built from (tune.* options, tools/tuning_env.py).  "2b" = the
     128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations);
     "1s" / "2s" / "2sb" = the split-bf16 flavours (precision="bf16x3": S3 hand-offs, LDS-staged 1x1 phases, no tail
     kernel; "2sb": 128-frame blocks with blocked accumulation)."""
@@ -48,8 +48,9 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     blocked = "b" in ni
     s3 = "s" in ni
     ni = int(ni[0])
-    env = dict(os.environ, DR_KSPLIT_MAX="1", DR_TILE=f"32:{ni}", DR_PW_NW=str(2 * ni), DR_STACK_FL=str(ni),
-               DR_BLOCKED="2" if blocked else "1")
+    from tools import tuning_env
+    env = tuning_env.env_with(tune__ksplit_max=1, tune__tile=3200 + ni, tune__pw_nw=2 * ni, tune__stack_fl=ni,
+                              blocked_accumulation=2 if blocked else 1)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)] + (["bf16x3"] if s3 else []), env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -62,8 +63,8 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
             assert run["equal"], rec
             if run.get("chain"):      # whole chains: the tail kernel ran (or, switched off, did not)
                 # (an evaluation that needs several fused launches - sample chunks - keeps the separate tail launches)
-                # (DR_TAIL=0 - a forced-mode run of the suite - only changes the DEFAULT: runs that set the option carry "tail")
-                env_off = "tail" not in run and os.environ.get("DR_TAIL", "1") == "0"
+                # (DR_TEST_TUNE="fused_tail=0" - a forced-mode run of the suite - pins the option for every run)
+                env_off = tuning_env.forced("fused_tail", 1) == 0
                 want_tail = run.get("tail", 1) == 1 and rec["runs"][0]["launches"] == 1 and not env_off and not s3
                 assert (run["tail_launches"] >= 1) == want_tail, rec
 
@@ -160,7 +161,8 @@ def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
     wait before the LDS-DMA hand-over barrier in round 3 (25 % of the runs of the then 160-frame flavour)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DR_STACK_FL=flavour)
+    from tools import tuning_env
+    env = tuning_env.env_with(tune__stack_fl=int(flavour))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "xcd_stress.py")] + args, env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
@@ -205,9 +207,71 @@ def test_handoff_litmus_plain_stores_across_xcds_are_caught():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     from diffroll_amd import build
     lib = build.build(verbose=False, variant="fault2")
-    env = dict(os.environ, DR_LIB=lib, DR_STACK_FL="2")
+    from tools import tuning_env
+    env = tuning_env.env_with(dict(os.environ, DR_LIB=lib), tune__stack_fl=2)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "xcd_stress.py"), "--T", "500", "--reps", "12"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2000:])
     assert "mapping 1 repeatable: True" in r.stdout, r.stdout[-2000:]      # inside one XCD plain stores are fine ...
     assert "RESULT FAIL" in r.stdout, r.stdout[-2000:]                     # ... across XCDs they are not
+
+
+@pytest.mark.parametrize("accumulation", ["single_chain", "blocked"])
+def test_fused_tail_on_and_off_give_the_same_bits_with_natural_tile_selection(accumulation):
+    """at the bench geometry (16 guided clips x 125 frames) the first step of a chain - and every step with
+    fused_tail = 0 - runs layer 0's shared conv as a per-phase launch on 64-frame tiles (256 blocks: what the cost model
+    picks), the later steps run it inside the tail kernel.  Under accumulation='single_chain' (blocked_accumulation = 1:
+    the 128-frame stack keeps one chain per output) both must contract as ONE chain (GemmArgs::nofold64 / TailArgs::fold
+    = 0), under the default both in 32-channel blocks: the header's claim that fused_tail only changes the launch count."""
+    from tools import tuning_env
+    if tuning_env.is_forced("blocked_accumulation") or tuning_env.is_forced("fused_tail") or tuning_env.is_forced("fused_stack"):
+        pytest.skip("DR_TEST_TUNE pins the options this test switches")
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=512, residual_layers=3, kernel_size=9, timesteps=6)
+    p = R.synthetic_params(hp, seed=11)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, accumulation=accumulation)
+    g = torch.Generator().manual_seed(12)
+    B, Tn = 16, 125
+    wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+    x = torch.randn(B, 1, Tn, 88, generator=g)
+    noise = torch.randn(6, B, 1, Tn, 88, generator=g)
+    eng = m.engine
+    # (split-K off: the narrow projections behind the stack - M = 88 / 512 rows - would otherwise be cut in K through the
+    # workspace when they run as launches of their own, which is a different summation order from the tail kernel's by
+    # design; the option is process-wide, hence the restore)
+    eng.set_option("tune.ksplit_max", 1)
+    try:
+        t0 = eng.tail_launches
+        with_tail, _ = m.sample(x, wav, noise=noise)
+        assert eng.tail_launches > t0                              # the tail kernel is what ran
+        eng.set_option("fused_tail", 0)
+        t1 = eng.tail_launches
+        without, _ = m.sample(x, wav, noise=noise)
+        assert eng.tail_launches == t1
+    finally:
+        eng.set_option("tune.ksplit_max", 16)
+    assert torch.equal(with_tail, without)
+    with torch.no_grad():
+        ref = R.sample_chain(p, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    assert float((with_tail.cpu() - ref).abs().max()) <= 1e-5
+
+
+def test_set_precision_failure_leaves_the_engine_usable(monkeypatch):
+    """dr_set_precision commits the mode only after the split-bf16 packings exist, and a commit
+    made AFTER the switch rebuilds them before the next launch (check_ready) - no launch ever sees null packings."""
+    hp = dict(R.DEFAULT_HP)
+    hp.update(residual_channels=128, residual_layers=2, kernel_size=9, timesteps=4)
+    p = R.synthetic_params(hp, seed=5)
+    m = make_model(hp, p, sampler="cfdg_ddpm_x0", w=0.5, precision="bf16x3")
+    g = torch.Generator().manual_seed(2)
+    wav = 0.1 * torch.randn(2, 40 * 512, generator=g)
+    x = torch.randn(2, 1, 40, 88, generator=g)
+    noise = torch.randn(4, 2, 1, 40, 88, generator=g)
+    a, _ = m.sample(x, wav, noise=noise)
+    # new weights while the split precision is on: the re-commit drops the packings, the next call rebuilds them
+    p2 = R.synthetic_params(hp, seed=6)
+    m.load_state_dict(p2)
+    b, _ = m.sample(x, wav, noise=noise)
+    with torch.no_grad():
+        ref = R.sample_chain(p2, hp, "cfdg_ddpm_x0", x, wav, noise, w=0.5)
+    assert float((b.cpu() - ref).abs().max()) <= 1e-5 and not torch.equal(a, b)

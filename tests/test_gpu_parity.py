@@ -386,13 +386,14 @@ def test_batch_shard_invariance_injected_and_philox(full_model):
 
 
 def test_batch_shard_bitwise_without_splitk():
-    """With the contraction order pinned (split-K off; the override is read once per process, hence the
+    """With the contraction order pinned (split-K off: option tune.ksplit_max = 1, process-wide, hence the
     child process) sharding the batch changes nothing, bit for bit."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, torch
         torch.set_num_threads(min(16, torch.get_num_threads()))
         sys.path.insert(0, %r)
+        from tools import tuning_env; tuning_env.install()
         from oracle import diffroll_ref as R
         from tests.test_gpu_parity import make_model, _cfg2_inputs
         hp = dict(R.DEFAULT_HP); hp.update(kernel_size=9, timesteps=20)
@@ -406,7 +407,8 @@ def test_batch_shard_bitwise_without_splitk():
         ok = ok and torch.equal(full, torch.cat([lo, hi], 0))
         print("BITWISE", int(ok))
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DR_KSPLIT_MAX="1"), capture_output=True,
+    from tools import tuning_env
+    r = subprocess.run([sys.executable, "-c", code], env=tuning_env.env_with(tune__ksplit_max=1), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.strip().endswith("BITWISE 1"), r.stdout[-500:]
@@ -1086,11 +1088,12 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
     the direct-operand 1x1 at 64 .. 160 frames, split-K): force each one and hold it to the oracle on shapes
     that exercise ragged tails and every dilation."""
     import subprocess, sys, textwrap
-    # the tile override is read once per process: run each forced variant in a child process
+    # the tune.* options are process-wide: run each forced variant in a child process
     code = textwrap.dedent("""
         import sys, torch, numpy as np
         torch.set_num_threads(min(16, torch.get_num_threads()))
         sys.path.insert(0, %r)
+        from tools import tuning_env; tuning_env.install()
         from oracle import diffroll_ref as R
         from tests.test_gpu_parity import make_model
         hp = dict(R.DEFAULT_HP); hp.update(residual_channels=128, residual_layers=4, kernel_size=9, timesteps=6)
@@ -1113,23 +1116,24 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
         print("HASH", digest.hexdigest())
         print("WORST", worst)
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    variants = [{"DR_TILE": t} for t in ("16:3", "16:5", "32:3", "32:5", "32:2", "32:1")]
+    from tools import tuning_env
+    variants = [{"tune__tile": t} for t in (1603, 1605, 3203, 3205, 3202, 3201)]
     # the 1x1 kernel flavours: direct-operand pw_kernel at every block width, the LDS-staged kernel, no split-K
-    variants += [{"DR_PW_NW": n} for n in ("2", "3", "4", "5")] + [{"DR_PW": "0"}, {"DR_KSPLIT_MAX": "1"}]
+    variants += [{"tune__pw_nw": n} for n in (2, 3, 4, 5)] + [{"tune__pw": 0}, {"tune__ksplit_max": 1}]
     for var in variants:
-        env = dict(os.environ, **var)
+        env = tuning_env.env_with(**var)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (var, r.stderr[-2000:])
         worst = float(r.stdout.strip().split("WORST")[-1])
         assert worst <= ATOL_FWD, (var, worst)
     # the 32x32-MFMA conv flavours (64 / 96 / 128 / 160-frame blocks) all accumulate in the same 32-channel blocks: with K
     # splitting and the fused stack out of the way they produce the same bits
-    if os.environ.get("DR_BLOCKED", "2") != "2":
+    if tuning_env.forced("blocked_accumulation", 2) != 2:
         return              # (blocked_accumulation = 1: 128-frame blocks keep one chain, 96 / 160 fall back to the 16x16 kernels)
     hashes = {}
-    for t in ("32:1", "32:2", "32:3", "32:5"):
-        env = dict(os.environ, DR_TILE=t, DR_KSPLIT_MAX="1", DR_STACK="0")
+    for t in (3201, 3202, 3203, 3205):
+        env = tuning_env.env_with(tune__tile=t, tune__ksplit_max=1, fused_stack=0)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (t, r.stderr[-2000:])
         hashes[t] = r.stdout.split("HASH")[-1].split()[0]
-    assert hashes["32:1"] == hashes["32:2"] == hashes["32:3"] == hashes["32:5"], hashes
+    assert hashes[3201] == hashes[3202] == hashes[3203] == hashes[3205], hashes

@@ -132,8 +132,8 @@ def test_unchecked_timeout_is_loud_at_the_consume_point_and_heals():
 def test_two_engines_on_two_streams_both_match_the_oracle():
     """Two engines computing on ONE device at the same time from two host threads / two streams - what the fused
     kernel's residency assumption does not cover.  Each launch fills the whole chip (32 evaluations x 8 M tiles), so
-    the two kernels' workgroups compete for CUs; whatever the dispatcher does (serialise them, or strand both until
-    the spin bound and fall back), BOTH callers must get oracle-correct rolls from their single sample() call."""
+    the two kernels' workgroups compete for CUs.  BOTH callers must get oracle-correct rolls from their single sample()
+    call, and (round 5) without a time-out: the second engine to arrive yields (abi.hip: FusedSlot)."""
     hp = dict(R.DEFAULT_HP)
     hp.update(residual_layers=3, timesteps=6)
     models, inputs, refs = [], [], []
@@ -175,6 +175,9 @@ def test_two_engines_on_two_streams_both_match_the_oracle():
         t.join(timeout=600)
     assert not errors, errors
     assert time.perf_counter() - t0 < 300.0
+    # (round 5) nobody ran into the ~1 s spin bound: the engines take turns on the device's fused slot - the one that finds
+    # the other's fused work still in flight yields to per-phase launches instead of gambling on co-residency
+    assert [m.engine.fallbacks for m in models] == [0, 0]
     for i in range(2):
         for rnd in range(4):
             assert results[i][rnd] is not None
@@ -205,7 +208,7 @@ def test_config2_real_batch_200_step_chain_vs_oracle():
     roll, _ = m.sample(x, wav, noise=noise)
     m.engine.stack_status()
     import os
-    if os.environ.get("DR_STACK", "1") != "0":                          # (DR_STACK=0: a forced-mode run of the suite)
+    if __import__("tools.tuning_env").tuning_env.forced("fused_stack", 1) != 0:                          # (DR_TEST_TUNE="fused_stack=0": a forced-mode run of the suite)
         assert m.engine.stack_launches >= 1                             # the fused kernel is what ran
     assert m.engine.fallbacks == 0
     with torch.no_grad():
@@ -318,7 +321,7 @@ def test_part_filled_launches_vs_oracle(sampler, B, Tn):
     out = m.reverse_diffusion(x, w_arg, 61, noise=z)[0].cpu()
     eng.stack_status()
     import os
-    if os.environ.get("DR_STACK", "1") == "1":
+    if __import__("tools.tuning_env").tuning_env.forced("fused_stack", 1) == 1:
         assert eng.stack_launches == n0                      # the per-phase kernels ran (the launch fills < 80 % of the CUs)
     assert maxdiff(out, ref) <= ATOL_STEP, (sampler, B, Tn)
     again = m.reverse_diffusion(x, w_arg, 61, noise=z)[0].cpu()
@@ -360,7 +363,7 @@ def _denoise64(p, hp, x, spec, t):
 TRAINED_GEOMETRIES = [
     # (k, B, T, fused_stack option, conv accumulates blocked?)     which kernels the launch heuristics pick there
     (9, 32, 125, 1, False),   # fused stack, 128-frame blocks: 32 evaluations in one forward - the flavour a guided batch of 16 (the
-                              # bench geometry) runs; blocked unless blocked_accumulation = 1 (DR_BLOCKED=1)
+                              # bench geometry) runs; blocked unless blocked_accumulation = 1 (DR_TEST_TUNE="blocked_accumulation=1")
     (9, 16, 125, 1, True),    # fused stack, 64-frame blocks (16 evaluations: BASELINE config 3's shape)
     (9, 16, 125, 0, True),    # per-phase: 64-frame 32x32-MFMA conv tiles + direct-from-L2 1x1
     (9, 8, 125, 1, True),     # fused stack, 64-frame blocks, half the chip
@@ -368,7 +371,7 @@ TRAINED_GEOMETRIES = [
     (15, 2, 640, 0, False),   # 16x16-MFMA conv tiles (160-frame blocks, unblocked) or 64-frame tiles cut in K, 160-frame 1x1
     (9, 3, 77, 0, True),      # ragged: 96-frame flavours / small launches
     (9, 8, 640, 0, "wide"),   # the reference's shipping geometry (4 guided 640-frame clips): 160-frame blocks - the 32x32-MFMA
-                              # flavour with blocked accumulation (round 4), the 16x16-MFMA one (one chain) with DR_BLOCKED=1
+                              # flavour with blocked accumulation (round 4), the 16x16-MFMA one (one chain) with blocked_accumulation = 1
 ]
 
 
@@ -387,7 +390,7 @@ def test_trained_regime_battery_vs_float64_oracle(precision, scale):
     cases above) it is 6 x (observed 3 - 3.9 x: legitimate rounding; a wrong saturation or a lost partial is orders of
     magnitude)."""
     import os
-    blocked_all = os.environ.get("DR_BLOCKED", "2") == "2"
+    blocked_all = __import__("tools.tuning_env").tuning_env.forced("blocked_accumulation", 2) == 2
     s_conv, s_out = scale
     margins = []
     for (k, B, Tn, fused, blocked) in TRAINED_GEOMETRIES:
@@ -450,7 +453,7 @@ def test_trained_regime_guided_steps_along_a_chain_vs_float64_oracle():
     worst = 0.0
     ratios = []
     import os
-    blocked = os.environ.get("DR_BLOCKED", "2") == "2"      # (DR_BLOCKED=1: the rounds 1-3 numerics, for the record)
+    blocked = __import__("tools.tuning_env").tuning_env.forced("blocked_accumulation", 2) == 2      # (blocked_accumulation = 1: the rounds 1-3 numerics, for the record)
     bound = 2.5 if blocked else 6.0
     for t in range(11, -1, -1):
         z = noise[t] if t > 0 else None
@@ -481,8 +484,8 @@ def test_accumulation_kwarg_selects_the_conv_numerics():
     fp32 chain on 128-frame blocks (the rounds 1-3 numerics): other bits, the same answer to fp32 round-off; any other
     value is rejected by the constructor."""
     import os
-    if "DR_BLOCKED" in os.environ:
-        pytest.skip("DR_BLOCKED overrides the 'auto' default")
+    if __import__("tools.tuning_env").tuning_env.is_forced("blocked_accumulation"):
+        pytest.skip("DR_TEST_TUNE pins blocked_accumulation: the 'auto' default cannot be observed")
     hp = dict(R.DEFAULT_HP)
     hp.update(residual_layers=3, timesteps=20)
     p = R.synthetic_params(hp, seed=5)

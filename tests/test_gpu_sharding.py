@@ -188,14 +188,15 @@ flag, _ = m.engine.stack_status()
 dist.barrier()
 if rank == 0:
     torch.save(out, sys.argv[4])
-print("RANK_DONE", rank, flag, m.engine.stack_launches)
+print("RANK_DONE", rank, flag, m.engine.stack_launches, m.engine.fallbacks)
 dist.destroy_process_group()
 """
 
 
 def test_two_processes_share_the_gpu_and_gather(tmp_path):
     """A real 2-process job on the ONE leased GPU (gloo rendezvous, host-side gather): each rank runs its 7-clip shard
-    through its own engine - two processes' fused kernels time-share the chip - and every rank returns the full
+    through its own engine - the processes find each other in the driver's process list and stop fusing (no
+    time-out, round 5) - and every rank returns the full
     batch, equal to the unsharded result of a single process.  (The RCCL flavour of the same job needs two GPUs.)"""
     from diffroll_amd.distributed import sample_sharded
     from diffroll_amd.launch import free_port
@@ -210,9 +211,9 @@ def test_two_processes_share_the_gpu_and_gather(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "RANK_DONE" in so, (so[-1500:], se[-3000:])
         done = [ln for ln in so.splitlines() if ln.startswith("RANK_DONE")][-1].split()
-        assert done[2] == "0", so                       # no barrier time-out in either process
-        if os.environ.get("DR_STACK", "1") != "0":      # (DR_STACK=0: a forced-mode run of the suite)
-            assert int(done[3]) > 0, so                 # and the fused kernel is what ran (224 blocks per process)
+        assert done[2] == "0" and done[4] == "0", so    # no barrier time-out in either process, pending or healed: a process
+        #                                                 that sees the other one computing (csrc/tenants.h) yields to per-phase
+        #                                                 launches instead of running into the ~1 s spin bound
     got = torch.load(res)
     hp, p, m = _model(layers=3, steps=8, C=512)
     torch.manual_seed(5)

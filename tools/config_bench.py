@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # DR_TEST_TUNE="tune.stack_fl=2,..." pins engine options for this process
 import bench  # noqa: E402
 
 CONFIGS = {

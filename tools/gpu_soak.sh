@@ -14,8 +14,8 @@ echo "## tools/determinism_soak.py 600   (split-K path: small launches, every ch
 timeout 900 python tools/determinism_soak.py 600 2>&1 | tail -3
 echo "## tools/xcd_stress.py: block mapping 0 (groups spread over the XCDs) must reproduce mapping 1 bit for bit"
 for T in 500 640; do
-  echo "# DR_STACK_FL=2 --T $T --reps 40"
-  DR_STACK_FL=2 timeout 600 python tools/xcd_stress.py --T $T --B 4 --reps 40 2>&1 | tail -2
+  echo "# DR_TEST_TUNE=tune.stack_fl=2 --T $T --reps 40"
+  DR_TEST_TUNE=tune.stack_fl=2 timeout 600 python tools/xcd_stress.py --T $T --B 4 --reps 40 2>&1 | tail -2
 done
 echo "# --T 250 --B 8 --reps 40 (64-frame flavour)"; timeout 600 python tools/xcd_stress.py --T 250 --B 8 --reps 40 2>&1 | tail -2
 echo "# --T 500 --chain 20 --reps 10 (whole chains, tail kernel)"; timeout 900 python tools/xcd_stress.py --T 500 --B 4 --chain 20 --reps 10 2>&1 | tail -2
@@ -42,8 +42,8 @@ echo "## LITMUS builds (WRONG on purpose): the same stress must FAIL.  -DDR_FAUL
 for v in fault1 fault2; do
   L=$(python -m diffroll_amd.build --variant=$v | tail -1)
   for i in 1 2 3 4 5 6 7 8 9 10; do
-    echo "# $v run $i: DR_STACK_FL=2 --T 640 --reps 24"
-    DR_BLOCKED=2 DR_LIB=$L DR_STACK_FL=2 timeout 600 python tools/xcd_stress.py --T 640 --B 4 --reps 24 2>&1 | grep -E "RESULT|mapping 1 repeatable"
+    echo "# $v run $i: tune.stack_fl=2 --T 640 --reps 24"
+    DR_LIB=$L DR_TEST_TUNE=blocked_accumulation=2,tune.stack_fl=2 timeout 600 python tools/xcd_stress.py --T 640 --B 4 --reps 24 2>&1 | grep -E "RESULT|mapping 1 repeatable"
     # (fault1 = a bare s_barrier in the producers: tools/isa_audit.py -DDR_FAULT=1 finds the missing wait in every kernel
     # with an LDS-DMA hand-over; the whole-chain form runs the tail kernel too)
     if [ $v = fault1 ]; then

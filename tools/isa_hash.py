@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "diffroll_amd", "csrc")
 
 
 def device_sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("engine.hip", "comm.hip"))
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and f not in ("pack.hip", "plan.hip", "abi.hip", "debug_abi.hip", "comm.hip"))
 
 
 def compile_asm(src, extra=()):

@@ -4,7 +4,7 @@
 # then copy gpurun_out/prof/<round>_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter set per
 # pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
 set -u
-RD=${1:-r04}
+RD=${1:-r05}
 R=$PWD
 OUT=$R/${2:-gpurun_out/prof}
 mkdir -p "$OUT"
@@ -17,6 +17,12 @@ $PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline > "$OUT/bench_kt1.log" 2>&1
 $PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
 rm -rf "$OUT/kt1"
+# the other BASELINE configurations at their per-GPU shape: share_of_step_time of every bench line is reproducible from these
+for c in 3 4 5; do
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktc$c" -o bench -- python "$R/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/bench_kt$c.log" 2>&1
+$PS "$OUT/ktc$c" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, BASELINE config $c at its per-GPU shape; 3 timed-or-warm-up graph chains + the event-instrumented eager roofline pass)" > "$OUT/${RD}_kernel_stats_cfg$c.txt"
+rm -rf "$OUT/ktc$c"
+done
 for cfg in 1 2 3 4 5 6 7; do
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pf$cfg" -o pf -- python "$R/tools/step_loop.py" --config $cfg --iters 10 > "$OUT/pf$cfg.log" 2>&1
 echo "fetch cfg$cfg rc=$?"
@@ -45,7 +51,7 @@ timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "
 timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
 timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" --scale-json "$OUT/${RD}_scale.json" > "$OUT/${RD}_scale_table.txt" 2>&1
 # time-to-first-roll: round-3 behaviour re-enabled ("before") next to the current build, fresh process each
-{ for c in 1 2; do DR_PACK_THREADS=1 DR_S3_EAGER=1 timeout 300 python -m diffroll_amd.coldstart --config $c --json 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "before (serial packing, eager split-bf16 packings)", "record": /; s/$/}/'; done
+{ for c in 1 2; do timeout 300 python -m diffroll_amd.coldstart --config $c --json --tune tune.pack_threads=1 --tune tune.s3_eager=1 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "before (serial packing, eager split-bf16 packings)", "record": /; s/$/}/'; done
   for c in 1 2; do timeout 300 python -m diffroll_amd.coldstart --config $c --json 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "now", "record": /; s/$/}/'; done; } > "$OUT/${RD}_cold_start.json"
 head -14 "$OUT/${RD}_kernel_stats.txt"
 cat "$OUT"/${RD}_dominant_cfg*_traffic.json

@@ -1,5 +1,8 @@
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # DR_TEST_TUNE="tune.stack_fl=2,..." pins engine options for this process
 import bench
 dev = torch.device('cuda', 0)
 m = bench.build_model(dev)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Chain time of small guided batches (the launches the under-filled kernel choices apply to), for A/B runs under
-different DR_* overrides:    DR_PWK=0 python tools/small_batch_ab.py [--batches 1,2,3,4,6] [--T 125] [--steps 50]"""
+different tune.* options:    DR_TEST_TUNE=tune.pwk=0 python tools/small_batch_ab.py [--batches 1,2,3,4,6] [--T 125] [--steps 50]"""
 import argparse
 import os
 import sys
@@ -10,6 +10,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # DR_TEST_TUNE="tune.stack_fl=2,..." pins engine options for this process
 import bench  # noqa: E402
 
 

@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # DR_TEST_TUNE="tune.stack_fl=2,..." pins engine options for this process
 import bench  # noqa: E402
 
 
@@ -18,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--level", type=int, default=1, help="fused_stack option value (2 = forced, e.g. with DR_STACK_FL=5)")
+    ap.add_argument("--level", type=int, default=1, help="fused_stack option value (2 = forced, e.g. with DR_TEST_TUNE=tune.stack_fl=2)")
     ap.add_argument("--batch", type=int, default=0, help="override the configuration's batch (clips per GPU)")
     ap.add_argument("--k", type=int, default=0, help="override the configuration's kernel size (taps per 32-channel chunk)")
     args = ap.parse_args()

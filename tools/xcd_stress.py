@@ -2,7 +2,7 @@
 """Cross-XCD hand-off stress of the fused residual stack: deep (15-layer) full-width net, groups of 32 blocks (4 frame
 tiles per clip) - block mapping 1 (a group inside one XCD) is the reference, mapping 0 (a group spread over all XCDs:
 every hand-off write-through + L1-bypassing / invalidated loads) must reproduce it bit for bit, repeatedly.
-    python tools/xcd_stress.py [--T 500] [--B 4] [--reps 6] [--sampler cfdg_ddpm_x0]      (DR_STACK_FL=5 for the 160-frame flavour)"""
+    python tools/xcd_stress.py [--T 500] [--B 4] [--reps 6] [--sampler cfdg_ddpm_x0]      (DR_TEST_TUNE=tune.stack_fl=2 pins the 128-frame flavour)"""
 import argparse
 import os
 import sys
@@ -11,6 +11,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import tuning_env  # noqa: E402
+
+tuning_env.install()        # DR_TEST_TUNE="tune.stack_fl=2,..." pins engine options for this process
 import bench  # noqa: E402
 
 
