@@ -122,6 +122,29 @@ def pmc_traffic(kernel_tag):
     return None, "no committed PMC profile for this kernel"
 
 
+def membound_fractions(config):
+    """the HBM-roof fraction of every memory-bound kernel of the path at this configuration's
+    geometry, from the newest committed kernel-trace profile (tools/membound.sh -> profiles/r*_membound_kernels.json;
+    algorithmic bytes per launch / rocprofv3 average duration / 8 TB/s).  At the BASELINE sizes these kernels move
+    1-17 MB per launch and a launch costs 2-4 us: they are launch-latency-bound there ('large' = where they flatten)."""
+    import glob
+    size = {2: "cfg2", 4: "cfg2", 3: "cfg3", 5: "cfg5", 6: "cfg5", 7: "cfg7"}.get(config)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_membound_kernels.json")), reverse=True):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except Exception:       # noqa: BLE001
+            continue
+        out = {"source": os.path.basename(path), "peak_gbps": j.get("peak_gbps"),
+               "current_sources": j.get("csrc_digest") == csrc_digest()}
+        for key in (size, "large"):
+            if key and key in j.get("sizes", {}):
+                out[key] = {k: {"avg_us": v["avg_us"], "mb": round(v["bytes"] / 1e6, 2), "frac": v["frac"]}
+                            for k, v in j["sizes"][key]["kernels"].items()}
+        return out
+    return None
+
+
 def flops_per_frame_eval(k, C=512, Lr=15):
     """algorithmic FLOPs per frame per network evaluation (conditioner / embedding hoisted)."""
     return 2 * 88 * C + Lr * (2 * C * 2 * C * k + 2 * C * 2 * C) + 2 * C * C + 2 * C * 88
@@ -452,6 +475,8 @@ def main():
             "flops_per_launch": flops / max(launches, 1),
             "share_of_step_time": round((ms * 1e-3) / (dt / args.steps), 4),
         }
+    if rank == 0:
+        result["memory_bound_kernels"] = membound_fractions(args.config)
     if not args.no_split:
         # Opt-in split-bf16 precision (DR_PRECISION_BF16X3: every fp32 operand split exactly into three bf16
         # pieces, six piece products on the bf16 MFMA, fp32 accumulation - fp32-level error).

@@ -280,7 +280,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     int rc;
     {   // buffers below are reallocated only when a shape grows: synchronise just then (a previous call may still
         // be reading them), not on every call
-        const size_t mm_need0 = e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2;
+        const size_t mm_need0 = (e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2) + minmax_scratch_floats(B);
         const bool grow = (size_t)B * Lp > e->fe_cap_wav || (size_t)B * bp * TF > e->fe_cap_pow ||
                           (size_t)B * mel_planes * 4 * TF > e->fe_cap_log || (size_t)B * mel_planes * 4 * T > e->fe_cap_spec ||
                           mm_need0 > e->fe_cap_mm || (size_t)e->L * B * 2 * Cp * T > e->cond_cap;
@@ -290,8 +290,14 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     if ((size_t)B * bp * TF > e->fe_cap_pow) { if ((rc = dev_alloc(e, &e->power, (size_t)B * bp * TF))) return rc; e->fe_cap_pow = (size_t)B * bp * TF; }
     if ((size_t)B * mel_planes * 4 * TF > e->fe_cap_log) { if ((rc = dev_alloc(e, &e->logmel, (size_t)B * mel_planes * 4 * TF))) return rc; e->fe_cap_log = (size_t)B * mel_planes * 4 * TF; }
     if ((size_t)B * mel_planes * 4 * T > e->fe_cap_spec) { if ((rc = dev_alloc(e, &e->specP4, (size_t)B * mel_planes * 4 * T))) return rc; e->fe_cap_spec = (size_t)B * mel_planes * 4 * T; }
-    const size_t mm_need = e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2;
-    if (mm_need > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, mm_need))) return rc; e->fe_cap_mm = mm_need; }
+    // (min, max) per clip / per frame, followed by the per-clip partials + ticket words of the multi-block min-max
+    const size_t mm_vals = e->norm_framewise ? (size_t)B * TF * 2 : (size_t)B * 2;
+    const size_t mm_need = mm_vals + minmax_scratch_floats(B);
+    if (mm_need > e->fe_cap_mm) { if ((rc = dev_alloc(e, &e->mm, mm_need))) return rc; e->fe_cap_mm = mm_need; e->mm_scratch_off = mm_vals; }
+    else if (e->mm_scratch_off != mm_vals) {      // same buffer, other split: the ticket words must be zero where they now lie
+        HIPCHK(e, hipMemsetAsync(e->mm, 0, e->fe_cap_mm * sizeof(float), st));
+        e->mm_scratch_off = mm_vals;
+    }
     const size_t cond_need = (size_t)e->L * B * 2 * Cp * T;
     bool cond_moved = false;
     if (cond_need > e->cond_cap) { if ((rc = dev_alloc(e, &e->cond, cond_need))) return rc; e->cond_cap = cond_need; cond_moved = true; }
@@ -328,7 +334,7 @@ int dr_frontend(dr_engine* e, const float* d_wav, int B, int L, int T_roll, int 
     }
     // 4. imagewise min-max over the untrimmed TF frames, mask, trim
     if (e->norm_framewise) HIPCHK(e, launch_minmax_frame(e->logmel, e->mm, B, mel_planes, TF, NM, st));
-    else HIPCHK(e, launch_minmax(e->logmel, e->mm, B, mel_planes, TF, NM, st));
+    else HIPCHK(e, launch_minmax(e->logmel, e->mm, e->mm + e->mm_scratch_off, B, mel_planes, TF, NM, st));
     HIPCHK(e, launch_normalize(e->logmel, e->mm, e->specP4, d_spec_out, B, mel_planes, mel_planes, TF, T, NM,
                                mask_t0, mask_t1, mask_f0, mask_f1, st, e->norm_framewise));
     // 5. hoisted conditioner projections, one (B, 2C, T) tensor per layer (model/diffwave.py:143)
@@ -619,10 +625,10 @@ int dr_frame_counts(dr_engine* e, const float* d_pred, const float* d_label, siz
     if (int rc = dr_pending_timeout(e, stream)) return rc;
     if (!e->d_counts) {
         void* q = nullptr;
-        HIPCHK(e, hipMalloc(&q, 3 * sizeof(unsigned long long)));
+        HIPCHK(e, hipMalloc(&q, frame_counts_work_words() * sizeof(unsigned long long)));
+        HIPCHK(e, hipMemset(q, 0, frame_counts_work_words() * sizeof(unsigned long long)));      // (the ticket word starts at zero)
         e->d_counts = (unsigned long long*)q;
     }
-    HIPCHK(e, hipMemsetAsync(e->d_counts, 0, 3 * sizeof(unsigned long long), st));
     HIPCHK(e, launch_frame_counts(d_pred, d_label, threshold, (long)n, e->d_counts, st));
     unsigned long long h[3];
     HIPCHK(e, hipMemcpyAsync(h, e->d_counts, sizeof h, hipMemcpyDeviceToHost, st));

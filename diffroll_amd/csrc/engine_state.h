@@ -111,7 +111,8 @@ struct dr_engine {
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     long long* dbg_ticks = nullptr;     // dr_bench_layer measurement hook
-    unsigned long long* d_counts = nullptr;   // dr_frame_counts accumulator
+    unsigned long long* d_counts = nullptr;   // dr_frame_counts: result words, ticket, per-block partials (update.hip)
+    size_t mm_scratch_off = 0;                // floats into `mm` where the multi-block min-max keeps its partials / tickets
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream)
     dr::DynParams* d_dyn = nullptr;         // per-call scalars of the captured chain (seed, batch offset, guidance weight)
     int* d_tsel = nullptr;              // per-sample steps of dr_forward_steps

@@ -24,8 +24,39 @@ __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restric
     out[(long)b * Lp + i] = v;
 }
 
+// the same, four outputs per lane: quads that lie inside the clip (all but the 2 * pad / 4 at its ends) are one aligned
+// float4 load + store (needs L % 4 == 0 and pad % 4 == 0: every configuration of config/spec/mel.yaml)
+__global__ __launch_bounds__(256) void reflect_pad4_kernel(const float* __restrict__ wav, float* __restrict__ out,
+                                                           int L, int pad, int Lp) {
+    const int b = blockIdx.y;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= Lp) return;
+    const float* w = wav + (long)b * L;
+    float4 v;
+    const int p = i - pad;
+    if (p >= 0 && p + 3 < L) {
+        v = *reinterpret_cast<const float4*>(w + p);
+    } else {
+        float e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int q = p + k;
+            if (q < 0) q = -q;
+            if (q >= L) q = 2 * (L - 1) - q;
+            e[k] = (i + k < L + 2 * pad) ? w[q] : 0.f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    *reinterpret_cast<float4*>(out + (long)b * Lp + i) = v;
+}
+
 hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pad, hipStream_t s) {
     const int Lp = (L + 2 * pad + 3) & ~3;
+    if ((L & 3) == 0 && (pad & 3) == 0 && (((uintptr_t)wav | (uintptr_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(reflect_pad4_kernel, dim3((unsigned)((Lp / 4 + 255) / 256), (unsigned)B), dim3(256), 0, s,
+                           wav, out, L, pad, Lp);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)((Lp + 255) / 256), (unsigned)B), dim3(256), 0, s,
                        wav, out, L, pad, Lp);
     return hipGetLastError();
@@ -132,21 +163,33 @@ hipError_t launch_stft_power(const float* wav_pad, const float* win, const float
     return hipGetLastError();
 }
 
-// per-sample min / max (model/utils.py:25-26) over the n_rows x TF valid values; wavefront shuffles
-// then one LDS hop across the 4 waves.
-__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, float* __restrict__ mm,
+// per-sample min / max (model/utils.py:25-26) over the n_rows x TF valid values.  A clip's log-mel (119 KB at 125 frames,
+// 595 KB at 640) is cut over MINMAX_CHUNKS-at-most workgroups (~32 KB each; until round 5 ONE workgroup walked a whole
+// clip: 16 CUs busy, 14 us at 16 x 125 frames, 61 us at 4 x 640): wavefront shuffles, one LDS hop across the 4 waves, the
+// chunk's (min, max) parked in scratch, a ticket per clip; the workgroup that draws the last ticket folds the chunks.
+// min / max are exact whatever the order: bit-identical to the single-workgroup form.
+constexpr int MINMAX_CHUNKS = 32;
+size_t minmax_scratch_floats(int B) { return (size_t)B * (2 * MINMAX_CHUNKS + 1); }
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, float* __restrict__ mm, float* __restrict__ scratch,
                                                      int planes, int TF, int n_rows) {
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, ck = blockIdx.x, nck = gridDim.x;
     const float4* xb = reinterpret_cast<const float4*>(x) + (long)b * planes * TF;
     const int vplanes = (n_rows + 3) >> 2;
+    const long total = (long)vplanes * TF;
+    const long per = (total + nck - 1) / nck;
+    const long i1 = min(total, (ck + 1) * per);
     float mn = INFINITY, mx = -INFINITY;
-    for (long i = threadIdx.x; i < (long)vplanes * TF; i += 256) {
-        const int pl = (int)(i / TF);
+    // only the LAST valid plane can hold rows >= n_rows (229 mel rows = 57 planes + 1 row): no division in the loop
+    const long last0 = (long)(vplanes - 1) * TF;
+    const int tail = n_rows - (vplanes - 1) * 4;             // valid rows of the last plane (1..4)
+#pragma unroll 4
+    for (long i = ck * per + threadIdx.x; i < i1; i += 256) {
         const float4 v = xb[i];
         const float vv[4] = {v.x, v.y, v.z, v.w};
+        const int valid = i >= last0 ? tail : 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (pl * 4 + e < n_rows) { mn = fminf(mn, vv[e]); mx = fmaxf(mx, vv[e]); }
+            if (e < valid) { mn = fminf(mn, vv[e]); mx = fmaxf(mx, vv[e]); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -156,10 +199,24 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x
     __shared__ float smn[4], smx[4];
     if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        mm[b * 2 + 0] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-        mm[b * 2 + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    if (threadIdx.x != 0) return;
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    if (nck == 1) { mm[b * 2 + 0] = mn; mm[b * 2 + 1] = mx; return; }
+    float* part = scratch + (long)b * (2 * MINMAX_CHUNKS + 1);
+    unsigned* ticket = reinterpret_cast<unsigned*>(part + 2 * MINMAX_CHUNKS);
+    __hip_atomic_store(part + 2 * ck, mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 2 * ck + 1, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (stores -> s_waitcnt vmcnt(0) -> relaxed ticket -> agent-scope loads: as the split-K reduction of gemm_body.h)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nck - 1) return;
+    for (int k = 0; k < nck; ++k) {
+        mn = fminf(mn, __hip_atomic_load(part + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        mx = fmaxf(mx, __hip_atomic_load(part + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
+    mm[b * 2 + 0] = mn;
+    mm[b * 2 + 1] = mx;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 'framewise' normalisation (model/utils.py:11-19): min / max over the n_rows frequency bins of every frame;
@@ -188,8 +245,12 @@ hipError_t launch_minmax_frame(const float* logmel, float* mm, int B, int planes
     return hipGetLastError();
 }
 
-hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s) {
-    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)B), dim3(256), 0, s, logmel, mm, planes, TF, n_rows);
+hipError_t launch_minmax(const float* logmel, float* mm, float* scratch, int B, int planes, int TF, int n_rows, hipStream_t s) {
+    const long bytes = (long)((n_rows + 3) >> 2) * TF * 16;
+    long chunks = (bytes + 32767) / 32768;
+    chunks = chunks < 1 ? 1 : (chunks > MINMAX_CHUNKS ? MINMAX_CHUNKS : chunks);
+    if (!scratch) chunks = 1;
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)chunks, (unsigned)B), dim3(256), 0, s, logmel, mm, scratch, planes, TF, n_rows);
     return hipGetLastError();
 }
 

@@ -442,6 +442,7 @@ hipError_t init_kernels() {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<5, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<3, 1, EPI_GATE, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = init_frontend_kernels()) != hipSuccess) return e;
+    if ((e = init_update_kernels()) != hipSuccess) return e;
     if ((e = init_tail_kernels()) != hipSuccess) return e;
     if ((e = init_stack_kernels()) != hipSuccess) return e;
     return init_gemm16();

@@ -256,8 +256,10 @@ hipError_t launch_reflect_pad(const float* wav, float* out, int B, int L, int pa
 // tw (N complex) = exp(-2 pi i k / N), norm = sqrt(sum win^2) (the spectrum is divided by it)
 hipError_t launch_stft_power(const float* wav_pad, const float* win, const float* tw, float* power, int B, int Lp, int TF,
                              int N, int hop, int bins_p, float norm, hipStream_t s);
-// per-sample min/max of logmel P4 [B][planes][TF][4] over rows < n_rows -> mm[B][2]
-hipError_t launch_minmax(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
+// per-sample min/max of logmel P4 [B][planes][TF][4] over rows < n_rows -> mm[B][2]; scratch = minmax_scratch_floats(B)
+// floats of device memory, zero before its first use (partials + one ticket word per sample, left zero by the kernel)
+hipError_t launch_minmax(const float* logmel, float* mm, float* scratch, int B, int planes, int TF, int n_rows, hipStream_t s);
+size_t minmax_scratch_floats(int B);
 // normalise, mask, trim -> spec P4 [B][planes_out][T][4] (rows >= n_rows zero) and optional plain (B, n_rows, T)
 // framewise = 1: mm holds one (min, max) per (sample, frame) [B][TF][2] (launch_minmax_frame) instead of per sample
 hipError_t launch_minmax_frame(const float* logmel, float* mm, int B, int planes, int TF, int n_rows, hipStream_t s);
@@ -272,8 +274,11 @@ hipError_t launch_noise_mix(int mode, const float* x, const float* y, const int6
 // roll (B, T, 88) thresholded at thr; a note = maximal run of frames above the threshold (rule1 with
 // onsets == frames, task/diffusion.py:1185-1233)
 hipError_t launch_note_runs(const float* roll, int* note_end, int B, int T, float thr, hipStream_t s);
-// counts[0..2] += {TP, FP, FN} of (pred > thr) against (label > 0.5) over n elements (exact integers)
+// work[0..2] = {TP, FP, FN} of (pred > thr) against (label > 0.5) over n elements (exact integers); work = device
+// scratch of frame_counts_work_words() 64-bit words, zero before its first use (the kernel leaves its ticket word zero)
 hipError_t launch_frame_counts(const float* pred, const float* label, float thr, long n,
-                               unsigned long long* counts, hipStream_t s);
+                               unsigned long long* work, hipStream_t s);
+size_t frame_counts_work_words();
+hipError_t init_update_kernels();
 
 }  // namespace dr

@@ -1137,3 +1137,99 @@ def test_flexible_width_tiles_vs_oracle(monkeypatch):
         assert r.returncode == 0, (t, r.stderr[-2000:])
         hashes[t] = r.stdout.split("HASH")[-1].split()[0]
     assert hashes[3201] == hashes[3202] == hashes[3203] == hashes[3205], hashes
+
+
+# --------------------------------------------------------------------------------------------
+# round 5: the rewritten memory-bound kernels (multi-block min-max, bit-mask note scan, ticketed frame counts, float4
+# q_sample) against plain numpy / torch at sizes that exercise every path of theirs
+# --------------------------------------------------------------------------------------------
+def _note_end_numpy(roll, thr):
+    """note_end[b, t, p] = end (exclusive) of the run of frames > thr that STARTS at t, else 0."""
+    on = roll > thr
+    B, Tn, P = on.shape
+    out = np.zeros((B, Tn, P), np.int32)
+    for b in range(B):
+        for p in range(P):
+            col = on[b, :, p]
+            t = 0
+            while t < Tn:
+                if col[t]:
+                    e = t
+                    while e < Tn and col[e]:
+                        e += 1
+                    out[b, t, p] = e
+                    t = e
+                else:
+                    t += 1
+    return out
+
+
+@pytest.mark.parametrize("B,Tn", [(3, 1), (2, 31), (2, 32), (2, 33), (5, 125), (2, 640), (1, 2049), (1, 12001)])
+def test_note_scan_bitmask_and_column_forms_vs_numpy(full_model, B, Tn):
+    """dr_note_runs: the one-workgroup-per-clip bit-mask scan (T <= 12000) and the column walk behind it (longer rolls)
+    against a plain run-length scan: word boundaries, a run that ends at T, all-on / all-off columns."""
+    hp, p, m = full_model
+    rng = np.random.default_rng(B * 100000 + Tn)
+    base = rng.random((B, Tn // 5 + 1, 88)) < 0.25
+    roll = np.repeat(base, 5, axis=1)[:, :Tn].astype(np.float32) * rng.uniform(0.51, 1.5, (B, Tn, 88)).astype(np.float32)
+    roll[:, :, 0] = 0.9                      # a note as long as the clip
+    roll[:, :, 1] = 0.1                      # silence
+    roll[:, -1, 2] = 0.9                     # a note that starts on the last frame
+    got = m.engine.note_runs(torch.from_numpy(roll), 0.5).cpu().numpy()
+    assert np.array_equal(got, _note_end_numpy(roll, 0.5))
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 8191, 8192, 176000, 2 * 1000 * 1000 + 3])
+def test_frame_counts_ticketed_blocks_vs_numpy(full_model, n):
+    """dr_frame_counts: 1 .. 256 blocks, float4 body + scalar tail, repeated calls (the ticket word re-arms itself)."""
+    hp, p, m = full_model
+    g = torch.Generator().manual_seed(n)
+    pred = torch.rand(n, generator=g)
+    label = (torch.rand(n, generator=g) > 0.8).float()
+    pn, ln = pred.numpy() > 0.5, label.numpy() > 0.5
+    want = (int((pn & ln).sum()), int((pn & ~ln).sum()), int((~pn & ln).sum()))
+    dev = m.engine.device
+    pd, ld = pred.to(dev), label.to(dev)
+    for _ in range(3):
+        assert m.engine.frame_counts(pd, ld, 0.5) == want
+    if n > 8:       # an unaligned view: the scalar path
+        pn, ln = pn[1:], ln[1:]
+        want = (int((pn & ln).sum()), int((pn & ~ln).sum()), int((~pn & ln).sum()))
+        assert m.engine.frame_counts(pd[1:], ld[1:], 0.5) == want
+
+
+@pytest.mark.parametrize("B,L", [(1, 64000), (2, 63999), (3, 327680), (2, 5 * 327680)])
+def test_multi_block_min_max_normalisation_vs_oracle(full_model, B, L):
+    """The per-clip min / max over 1 .. 32 workgroups (119 KB .. 3 MB of log-mel per clip), twice (tickets re-arm),
+    then a smaller batch in the same buffers (the scratch split moves)."""
+    hp, p, m = full_model
+    g = torch.Generator().manual_seed(L + B)
+    wav = 0.1 * torch.randn(B, L, generator=g)
+    Tn = L // 512
+    with torch.no_grad():
+        ref = R.frontend(wav, hp, Tn)
+    for _ in range(2):
+        spec = m.engine.frontend(wav, Tn).cpu()
+        assert maxdiff(spec, ref) <= ATOL_SPEC
+    spec1 = m.engine.frontend(wav[:1], Tn).cpu()
+    assert maxdiff(spec1, ref[:1]) <= ATOL_SPEC
+
+
+def test_q_sample_vector_and_scalar_paths_bit_exact():
+    """dr_q_sample / dr_extract_x0: float4 path (per-sample size a multiple of 4, aligned) and the scalar path (odd sizes,
+    unaligned views) against the torch expressions of task/diffusion.py:31-64, bit for bit."""
+    from diffroll_amd import q_sample, extract_x0
+    from diffroll_amd.schedule import make_schedule
+    sch = make_schedule(1e-4, 0.02, 200)
+    sac, s1m = sch["sqrt_alphas_cumprod"], sch["sqrt_one_minus_alphas_cumprod"]
+    g = torch.Generator().manual_seed(4)
+    for shape in ((4, 1, 125, 88), (3, 1, 7, 3), (2, 1, 640, 88)):
+        x0 = torch.rand(shape, generator=g)
+        z = torch.randn(shape, generator=g)
+        t = torch.randint(0, 200, (shape[0],), generator=g)
+        a = sac[t].reshape(-1, 1, 1, 1)
+        c = s1m[t].reshape(-1, 1, 1, 1)
+        xt = q_sample(x0.cuda(), t, sac, s1m, z.cuda()).cpu()
+        assert torch.equal(xt, a * x0 + c * z)
+        back = extract_x0(xt.cuda(), z.cuda(), t, sac, s1m).cpu()
+        assert torch.equal(back, (xt - c * z) / a)

@@ -63,7 +63,7 @@ def main():
         "size": args.size, "what": sz["what"], "B": B, "L": L, "T": T, "reps": args.reps,
         # ALGORITHMIC bytes per launch: every operand once
         "bytes": {
-            "reflect_pad_kernel": 4 * B * L + 4 * B * Lp,
+            "reflect_pad4_kernel": 4 * B * L + 4 * B * Lp,
             "stft_power_kernel": 4 * B * Lp + 4 * B * TF * 1088,                  # the padded clip once (frames overlap 4x) + the power rows
             "minmax_kernel": 16 * B * 58 * TF,                                    # 229 mel rows = 58 planes of 4
             "normalize_kernel": 16 * B * 58 * T + 16 * B * 58 * T + 4 * B * 229 * T,   # read log-mel, write P4 spec + the plain spec handed back

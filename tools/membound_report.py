@@ -16,7 +16,9 @@ COPY_CEILING = 0.79
 
 def main():
     root, out_json = sys.argv[1], sys.argv[2]
-    rec = {"peak_gbps": PEAK, "sizes": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec = {"peak_gbps": PEAK, "csrc_digest": bench.csrc_digest(), "sizes": {}}
     print("# HBM-roof fraction of the memory-bound kernels (SURVEY 8d item 2): ALGORITHMIC bytes per launch / rocprofv3 --kernel-trace")
     print("# average duration / 8 TB/s.  The guide's plain-copy ceiling is 0.79; an empty kernel launch shows as ~2-4 us in the same traces")
     print("# (set_dyn_kernel, one thread), i.e. a kernel moving less than ~10 MB cannot reach 0.3 of the roof whatever it does.")
