@@ -101,7 +101,6 @@ int clear_stack_timeout(dr_engine* e) {
     HIPCHK(e, hipMemset(e->stack_bar, 0, (size_t)(12 * dr_engine::STACK_GROUPS) * sizeof(unsigned)));    // all three counter arrays
     HIPCHK(e, hipMemset(e->stack_xid, 0xFF, 1024 * sizeof(unsigned)));
     HIPCHK(e, hipMemset(e->stack_derr, 0, 16 * sizeof(unsigned)));
-    if (e->pair_flag) HIPCHK(e, hipMemset(e->pair_flag, 0, (size_t)dr_engine::PAIRS * 8 * sizeof(unsigned)));      // equal within every pair again
     *e->stack_err_host = 0;
     return DR_OK;
 }
@@ -214,7 +213,6 @@ void dr_destroy(dr_engine* e) {
     if (e->d_counts) (void)hipFree(e->d_counts);
     if (e->d_dyn) (void)hipFree(e->d_dyn);
     if (e->stack_bar) (void)hipFree(e->stack_bar);
-    if (e->pair_ws) (void)hipFree(e->pair_ws);
     if (e->xsave) (void)hipFree(e->xsave);
     if (e->stack_err_host) (void)hipHostFree((void*)e->stack_err_host);
     if (e->stack_dbg) (void)hipFree(e->stack_dbg);
@@ -685,8 +683,8 @@ int dr_set_option(dr_engine* e, const char* name, int value) {
         Tuning& t = tuning();
         const std::string f = n.substr(5);
         int* field = f == "pack_threads" ? &t.pack_threads : f == "tile" ? &t.tile : f == "pw" ? &t.pw : f == "pw_nw" ? &t.pw_nw
-                   : f == "pwk" ? &t.pwk : f == "ksplit_max" ? &t.ksplit_max : f == "ksplit_force" ? &t.ksplit_force : f == "one_ks" ? &t.one_ks : f == "stack3" ? &t.stack3
-                   : f == "stack_fl" ? &t.stack_fl : f == "stack_pair" ? &t.stack_pair : f == "stack_pair_gain" ? &t.stack_pair_gain : f == "xcd_n" ? &t.xcd_n : f == "xcd_model" ? &t.xcd_model
+                   : f == "pwk" ? &t.pwk : f == "ksplit_max" ? &t.ksplit_max : f == "one_ks" ? &t.one_ks : f == "stack3" ? &t.stack3
+                   : f == "stack_fl" ? &t.stack_fl : f == "xcd_n" ? &t.xcd_n : f == "xcd_model" ? &t.xcd_model
                    : f == "s3_eager" ? &t.s3_eager : f == "debug_chunks" ? &t.debug_chunks : nullptr;
         if (f == "ksplit_blocks") { drop_graph(); t.ksplit_blocks = value; return DR_OK; }
         if (!field) return fail(e, DR_ENAME, "unknown option '%s'", name);

@@ -133,10 +133,6 @@ struct dr_engine {
     unsigned* stack_xid = nullptr;      // [1024] (generation, XCC id) tags published by the blocks of the last launch
     unsigned* tail_bar = nullptr;       // group / pair counters of the tail kernel (own arrays, same protocol)
     unsigned* tail_pbar = nullptr;
-    // pair-split flavour of the fused stack (stack_kernel<3>): exchange regions (64 KiB per pair) + hand-over words
-    static constexpr int PAIRS = 512;
-    float* pair_ws = nullptr;
-    unsigned* pair_flag = nullptr;
     int opt_tail = 1;                   // fused step: layer 0's shared conv inside the stack launch + the tail kernel
     int64_t tail_launches = 0;
     float* xalt = nullptr;              // the tail kernel writes x_{t-1} here (it must not update x_t in place: other

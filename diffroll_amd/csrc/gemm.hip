@@ -354,10 +354,6 @@ KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, i
         return (double)((tiles * ks + 255) / 256) * t_full / ks + (ks > 1 ? 4.0 + ks : 0.0);
     };
     KSplitPlan p{1, cost(1), cost(1)};
-    if (const int f = tuning().ksplit_force; f > 1 && taps > 1) {       // A/B and bit-identity tests: exactly f slices
-        if (nchunks % f == 0 && (size_t)tiles * f * 128 * BN <= ws_floats && (size_t)tiles * 4 <= ws_cnt_n) { p.ks = f; p.us = cost(f); }
-        return p;
-    }
     for (int ks = 2; ks <= ks_max && ks <= 16; ks *= 2) {
         if (tiles * ks > max_blocks || nchunks % ks != 0) break;
         if ((size_t)tiles * ks * 128 * BN > ws_floats || (size_t)tiles * 4 > ws_cnt_n) break;

@@ -53,15 +53,8 @@ namespace dr {
 //   hand-over barrier (see fold()): +0.6 % per config-3 chain on 64-frame blocks, +0.2-0.6 % per config-2 chain on 128-row x
 //   128-frame blocks (208 registers with the in-place fragment refresh below) - on by default in both (engine option
 //   "blocked_accumulation": 1 = 128-frame blocks keep one chain).  profiles/r04_conv_flavour_ab.txt.
-//   PAIR = 1 (stack_kernel<3> only: NI = 2, the gated conv, fp32): this block is one of TWO that share the 128-row x 128-frame
-//   tile (mt, nt); it contracts K half `ks` (a.ksplit = 2) and finishes frame half `ks`: after the K loop every consumer wave
-//   stores the two 32-frame tiles of the OTHER half into its exchange region (the hand-off form of hd / g: write-through
-//   unless the group shares an L2), drains, publishes its hand-over word, waits for its partner wave's, loads the partner's
-//   partial of its own half (sc1) and adds: (0 + p0) + p1, the sum order of the per-phase kernels' split-K x2 - bit-identical
-//   to gemm_kernel<2, 1, EPI_GATE, 0, 1> launched with ksplit = 2.  No block-level barrier, no ticket: wave w talks to wave w.
-template <int NI, int KS, int EPI, int PREC, int COH, int FOLDP = (NI == 1), int PAIR = 0>
+template <int NI, int KS, int EPI, int PREC, int COH, int FOLDP = (NI == 1)>
 DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int nt, const int ks) {
-    static_assert(!PAIR || (NI == 2 && KS == 1 && EPI == EPI_GATE && PREC == 0 && COH == 1), "pair-split: the fused 128-frame gated conv");
     // NI = 1 / 2: 64 / 128-frame blocks (2 / 4 32-frame MFMA tiles per consumer wave); NI = 3 / 5: THREE / FIVE tiles = 96 /
     // 160-frame blocks, the dilated conv only (640-frame geometries: 4 x 160-frame blocks per clip, 8 evaluations x 4 x 8 M
     // tiles = 256 blocks; ragged lengths: 96) - fp32 with blocked accumulation, in place of the 16x16-MFMA kernels of those
@@ -523,58 +516,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // stores -> s_waitcnt vmcnt(0) -> ticket (agent-scope atomic) -> loads; a full __threadfence() here
     // costs an L2-wide write-back + invalidate per wave (measured: 25 us per launch).
     // ----------------------------------------------------------------------------------------
-    if constexpr (PAIR) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        float* mine = a.pair_ws + ((long)(a.pair_id * 2 + ks) * 4 + wave) * 2048;            // 8 KiB per (pair, sender, wave)
-        const float* theirs = a.pair_ws + ((long)(a.pair_id * 2 + (1 - ks)) * 4 + wave) * 2048;
-        auto send = [&](auto N0) {
-            constexpr int n0 = decltype(N0)::value;
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    store_f4<1>(mine + ((tl * 4 + q) * 64 + lane) * 4,
-                                make_float4(acc[0][n0 + tl][4 * q], acc[0][n0 + tl][4 * q + 1], acc[0][n0 + tl][4 * q + 2], acc[0][n0 + tl][4 * q + 3]),
-                                a.wt_store);
-        };
-        if (ks == 0) send(std::integral_constant<int, 2>{}); else send(std::integral_constant<int, 0>{});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the partials are out before the word is published
-        if (lane == 0) {
-            __hip_atomic_store(a.pair_flag + (a.pair_id * 2 + ks) * 4 + wave, a.pair_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned* pf = a.pair_flag + (a.pair_id * 2 + (1 - ks)) * 4 + wave;
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(pf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pair_target) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-                if (spins > (1u << 22) ||
-                    ((spins == 256u || (spins & 16383u) == 0) && __hip_atomic_load(a.pderr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    __hip_atomic_store(a.perr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    __hip_atomic_store(a.pderr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)theirs, 0, 8192u, 0x00020000);
-        u32x4 got[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) got[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, lane * 16, j * 1024, 16);      // sc1: as hd
-        auto recv = [&](auto N0) {        // (0 + p0) + p1, whichever half is this block's own
-            constexpr int n0 = decltype(N0)::value;
-#pragma unroll
-            for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float o = acc[0][n0 + tl][4 * q + e], g = __uint_as_float(got[tl * 4 + q][e]);
-                        acc[0][n0 + tl][4 * q + e] = (n0 == 0) ? (0.f + o) + g : (0.f + g) + o;
-                    }
-        };
-        if (ks == 0) recv(std::integral_constant<int, 0>{}); else recv(std::integral_constant<int, 2>{});
-        if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[15] = clock64() - tick0;      // K loop + exchange (dr_stack_status tick 79)
-    }
-    if (!PAIR && a.ksplit > 1) {
+    if (a.ksplit > 1) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         constexpr int WQ = NW * 4;                                   // float4 per lane per wave region
         constexpr int WSCOH = 17;                                    // buffer cache policy: sc0 | sc1
@@ -668,7 +610,6 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         }
     #pragma unroll
         for (int ni = 0; ni < NW; ++ni) {
-            if constexpr (PAIR) { if ((ni >> 1) != ks) continue; }      // the other frame half is the partner's (block-uniform)
             const int t = t0 + wc * WFR + ni * 32 + r;
             if constexpr (EPI == EPI_RES_SKIP) {
     #pragma unroll

@@ -35,13 +35,10 @@ struct Tuning {
     int pw_nw = 0;           // force 32 * pw_nw frames per pw_kernel block (2..5); 0 = cost model
     int pwk = 1;             // under-filled 1x1 launches: K split over the block's waves (pwk_kernel)
     int ksplit_max = 16;     // largest split-K factor of gemm_kernel launches (1 = never split)
-    int ksplit_force = 0;    // > 1: dilated-conv launches (taps > 1) are cut into exactly this many K slices (the per-phase twin of the pair-split stack flavour)
     long ksplit_blocks = 0;  // cap on tiles x ksplit (0 = 2048 fp32 / 256 split-bf16)
     int one_ks = 0;          // force the 1x1 GEMMs' channels-per-hand-over (KS = 1 / 2 / 4); 0 = by divisibility
     int stack3 = 1;          // the split-bf16 flavour of the fused residual stack
-    int stack_fl = 0;        // force the fused stack's block flavour (1 = 64-frame, 2 = 128-frame blocks, 3 = 64-frame blocks with pair-split convs); 0 = cost model
-    int stack_pair = 1;      // the cost model may pick flavour 3
-    int stack_pair_gain = 15; // ... which it prices this many 1/1000 below flavour 1 (measured at BASELINE config 3)
+    int stack_fl = 0;        // force the fused stack's block flavour (1 = 64-frame, 2 = 128-frame blocks); 0 = cost model
     int xcd_n = -1;          // force the block -> XCD mapping of per-phase GEMM launches (0 / 1); -1 = traffic model
     int xcd_model = 1;       // 0 = the rounds 1-2 rule (activation bytes > weight bytes)
     int s3_eager = 0;        // build the split-bf16 packings at every dr_commit (rounds 1-3 behaviour)
@@ -113,16 +110,6 @@ struct GemmArgs {
                              // accumulation every other 64-frame launch uses - the shared first-layer conv of an engine whose fused
                              // 128-frame stack runs single-chain (blocked_accumulation = 1), so that the per-phase launch and the
                              // tail kernel's copy of that conv (TailArgs::fold = 0) produce the same bits
-    // pair-split conv of the fused residual stack (gemm_body<.., PAIR = 1>, stack_kernel<3>): two workgroups contract one half
-    // of K each for the same 128-row x 128-frame tile, swap the 64-frame half they do not finish and each runs the epilogue
-    // of its own half.  pair_ws: exchange regions [pair][sender][wave][8][64 lanes] float4 (8 KiB per wave); pair_flag:
-    // [pair][sender][wave] hand-over words (monotonic: a wave publishes pair_target after its stores have drained and waits
-    // for its partner's word to reach it); perr / pderr: the time-out flags of the launch (persistent.h)
-    float* pair_ws;
-    unsigned* pair_flag;
-    int pair_id;
-    unsigned pair_target;
-    unsigned *perr, *pderr;
     int wt_store;            // fused residual stack only (COH bodies): 1 = the tensors handed to other workgroups are
                              // stored write-through (sc1), 0 = plain stores (every workgroup of the group shares one
                              // XCD's L2, verified at run time)
@@ -187,8 +174,6 @@ struct StackArgs {
     int fault;                                // test hook: barriers wait for one arrival too many (exercises the spin bound)
     int fold128;                              // FL = 2: 1 = the instantiation with blocked accumulation in its conv phases
     int warm;                                 // idle waves warm the L2 with the next phase's weights / conditioner tile
-    float* pair_ws;                           // FL = 3: exchange regions of the K-split pairs (GemmArgs::pair_ws), >= pairs x 64 KiB
-    unsigned* pair_flag;                      // FL = 3: [pairs][2][4] hand-over words, equal within a pair between launches
     unsigned* xid;                            // [grid] scratch: the XCC each block runs on (rewritten by every launch)
     unsigned* bar;                            // [groups][4] {arrivals, departures, generation, -}; the first two are zero
                                               // between launches, the generation advances by one per launch
@@ -199,8 +184,7 @@ struct StackArgs {
     long long* dbg;                           // optional: block 0 writes s_memtime at every phase start (dbg[p - p0]) and at the end
     StackLayer layer[DR_STACK_MAX_LAYERS];
 };
-// FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames; 3 = 64-frame blocks whose conv phases run PAIR-SPLIT (two
-// blocks share a 128-frame conv tile, half of K each: stack.hip).  The caller guarantees
+// FL = block flavour: 1 / 2 = 128 packed rows x 64 / 128 frames.  The caller guarantees
 // NB * stack_group_blocks(FL, Cp, T) <= #CUs and stack_lds_bytes(..) <= 160 KiB.
 // prec = 1: the split-bf16 flavour (s.hd / s.g = the S3 tensors; Cp % 128 == 0; LDS: stack3_lds_bytes)
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st, int prec = 0);

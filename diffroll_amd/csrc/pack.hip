@@ -469,14 +469,6 @@ int commit(dr_engine* e, hipStream_t st) {
         hipDeviceProp_t prop;
         HIPCHK(e, hipGetDeviceProperties(&prop, e->cfg.device));
         e->n_cus = prop.multiProcessorCount;
-        {   // pair-split flavour: 64 KiB of exchange space per pair + its 8 hand-over words (zero = equal within every pair)
-            void* pw = nullptr;
-            const size_t bytes = (size_t)dr_engine::PAIRS * 65536 + (size_t)dr_engine::PAIRS * 8 * sizeof(unsigned);
-            HIPCHK(e, hipMalloc(&pw, bytes));
-            HIPCHK(e, hipMemset((char*)pw + (size_t)dr_engine::PAIRS * 65536, 0, (size_t)dr_engine::PAIRS * 8 * sizeof(unsigned)));
-            e->pair_ws = (float*)pw;
-            e->pair_flag = (unsigned*)((char*)pw + (size_t)dr_engine::PAIRS * 65536);
-        }
     }
     {   // hoisted step embedding: table -> Linear+silu -> Linear+silu -> per-layer Linear, with
         // "frames" = diffusion steps (model/diffwave.py:65-74, :126,:138).  Built on the device by

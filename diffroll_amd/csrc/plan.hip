@@ -229,10 +229,8 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             return best;
         };
         double best = 1e30;
-        for (int fl : {1, 2, 3}) {
+        for (int fl : {1, 2}) {
             if (fl_force && fl != fl_force) continue;
-            // flavour 3 (64-frame blocks, conv phases pair-split on 128-frame tiles): exact fp32 with blocked accumulation
-            if (fl == 3 && (prec != 0 || e->opt_blocked < 2 || !e->pair_ws || !(fl_force == 3 || tuning().stack_pair))) continue;
             const int bn = stack_tile_frames(fl);
             const long gsize = stack_group_blocks(fl, Cp, T);                           // blocks per sample
             const long cap = std::min<long>(e->n_cus, 1024) / gsize;                    // samples per launch
@@ -241,8 +239,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
-            // (flavour 3 = flavour 1's tiling with a cheaper conv phase: tune.stack_pair_gain, measured at config 3)
-            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 2 ? 1.0 : 1.0 / 0.93) * (fl == 3 ? 1.0 - 0.001 * tuning().stack_pair_gain : 1.0);
+            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : 1.0);
             // (a single launch that leaves more than a fifth of the CUs idle is better served by the per-phase kernels'
             // split-K, which this cost model does not see: they cut the same work into many short blocks that balance
             // over all CUs - 8 evaluations x 125 frames (half the chip): 1365 vs 2422 us per step, 10 / 12 evaluations
@@ -297,7 +294,6 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             sa.fault = e->opt_stack_fault;
             sa.fold128 = e->opt_blocked >= 2;
             sa.bar = e->stack_bar; sa.err = e->stack_err; sa.derr = e->stack_derr; sa.xid = e->stack_xid;
-            sa.pair_ws = e->pair_ws; sa.pair_flag = e->pair_flag;
             sa.dbg = e->stack_dbg_on ? e->stack_dbg : nullptr;
             for (int l = 0; l < L; ++l) {
                 const LayerW& w = e->layers[l];

@@ -13,13 +13,7 @@ DR_BOUNDS_TU(stack)
 // frames with K split over the block's wave pairs, round 4, for BASELINE config 3's 16 evaluations x 125 frames - every
 // wave then runs the 128-frame instruction stream, but a 64-row block stages the same X tile for half the MFMAs and the
 // doubled LDS-DMA traffic makes it 4 % slower than 64-frame blocks: profiles/r04_conv_flavour_ab.txt.)
-// FL = 3 (round 5, BASELINE config 3: 16 evaluations x 125 frames): 64-frame blocks like flavour 1 - resident tile, 1x1
-// phases, grid - whose CONV phases run pair-split: blocks (mt, 64-frame tile 2j) and (mt, tile 2j + 1) share the 128-frame
-// conv tile j, each contracts one half of K on the 128-frame instruction stream (66.7 cycles per MFMA, half the X bytes per
-// MFMA of a 64-frame block), then the pair swaps the 64-frame half it does not finish (gemm_body<.., PAIR = 1>: 32 KB each
-// way per block, wave to wave) and each block gates its own 64 frames.  (0 + p0) + p1: bit-identical to the per-phase conv
-// launched with ksplit = 2 on 128-frame tiles.
-// FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavours 1 and 3, on request for flavour 2.
+// FOLDP: blocked accumulation in the conv phases (gemm_body.h) - always for flavour 1, on request for flavour 2.
 // PREC = 1: the split-bf16 ("S3") precision - s.hd / s.g are the S3 tensors hd3 / g3 ([sample][piece][channel/8][frame][8
 // bf16]); the conv phase is gemm_body<.., PREC = 1> (S3 in, S3 out), the 1x1 phase the LDS-staged S3 GEMM (gemm_body<1, 4,
 // EPI_RES_SKIP, 1>) on the block's 64-frame tile(s), which re-reads its h / skip tile from global every layer (nothing is
@@ -36,17 +30,14 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
     const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) StackArgs& s = *sp;
-    static_assert(FL == 1 || FL == 2 || (FL == 3 && PREC == 0 && FOLDP == 1), "block flavours");
-    constexpr bool PAIR = FL == 3;
-    constexpr int BN = FL == 2 ? 128 : 64;                 // frames of the block's resident tile and 1x1 phases
+    static_assert(FL == 1 || FL == 2, "block flavours");
+    constexpr int BN = 64 * FL;
     constexpr int RP = 32;                                 // planes (4 rows each) of the block's resident tile
     constexpr int RWL = (BN + 63) / 64;                    // 64-frame segments of a tile row
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int MT = s.Cp >> 6;                              // 128-row M tiles of the 2 Cp packed rows
     const int MB = MT;                                     // blocks per frame tile
-    // (pair-split: an even number of 64-frame tiles per clip - a clip of 129..192 frames carries one tile of padding, whose
-    // block only takes part in the conv phases)
-    const int tps = PAIR ? 2 * ((s.T + 127) / 128) : (s.T + BN - 1) / BN;
+    const int tps = (s.T + BN - 1) / BN;
     const unsigned gsize = (unsigned)(MB * tps);          // blocks per group
     int mt, nt, grp, member;
     if (s.xcd_n) {       // all blocks of a group on one XCD (block b is dispatched to XCD b % 8): the group shares an L2
@@ -119,20 +110,6 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     // "not my XCD" and the group keeps the write-through stores that are valid under every placement.
     int wt_store = 1;
     unsigned my_tag = 0;
-    // pair-split: this block's pair and K half, and the value its waves' hand-over words hold at launch start (a wave's own
-    // word: written by itself in earlier launches; its partner's word is equal - every launch advances both by the number
-    // of conv phases it runs)
-    const int pair_id = PAIR ? (grp * (tps >> 1) + ((member / MB) >> 1)) * MT + mt : 0;
-    const int pair_ks = PAIR ? ((member / MB) & 1) : 0;
-    unsigned pair_base = 0, pair_ep = 0;
-    if constexpr (PAIR) {
-        if (wave < 4) {
-            unsigned v = 0;
-            if ((threadIdx.x & 63) == 0)
-                v = __hip_atomic_load(s.pair_flag + (pair_id * 2 + pair_ks) * 4 + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pair_base = __builtin_amdgcn_readfirstlane(v);
-        }
-    }
     unsigned& same_xcd_s = *reinterpret_cast<unsigned*>(Rs + RP * BN);      // one word behind the resident tile
     if (threadIdx.x == 0) {
         unsigned my_xcc;
@@ -198,15 +175,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             a.cond = ly.cond; a.cond2 = ly.cond2; a.c_bs = s.c_bs; a.n_cond = s.n_cond;
             a.Y = s.g;
             if (s.dbg && p + 2 >= s.p1) a.dbg = s.dbg + 64;       // last conv phase: body tick marks of block 0
-            if constexpr (PAIR) {
-                a.ksplit = 2;
-                a.pair_ws = s.pair_ws; a.pair_flag = s.pair_flag; a.pair_id = pair_id;
-                a.pair_target = pair_base + (++pair_ep);
-                a.perr = s.err; a.pderr = s.derr;
-                gemm_body<2, 1, EPI_GATE, 0, 1, 1, 1>(a, smem, mt, grp * (tps >> 1) + ((member / MB) >> 1), pair_ks);
-            } else {
-                gemm_body<FL, 1, EPI_GATE, 0, 1, FOLDP>(a, smem, mt, nt, 0);
-            }
+            gemm_body<FL, 1, EPI_GATE, 0, 1, FOLDP>(a, smem, mt, nt, 0);
             // The agent-scope acquire the NEXT phase needs (the 1x1 reads g, written by other workgroups, with plain
             // loads through this CU's L1): one producer wave issues it here, while the consumers still contract the
             // last chunk, instead of everyone waiting ~1.7 us for it behind the barrier.  It is valid anywhere
@@ -246,10 +215,6 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // the phase takes the same cycles at a lower clock (485.4 vs 483.3 ms).
             if constexpr (FL == 2) {
                 if (!idle) pw_body<2, 1, 1, 128>(a, mt, nt, wave & 3, Rs, (wave >> 2) * 64);
-            } else if constexpr (PAIR) {
-                // (pw_body numbers 64-frame tiles by ceil(T / 64) per clip; a padding tile has no frames)
-                const int tps64 = (s.T + 63) >> 6, ti = member / MB;
-                if (wave < 4 && !idle && ti < tps64) pw_body<2, 1, 1>(a, mt, grp * tps64 + ti, wave, Rs);
             } else {
                 if (wave < 4 && !idle) pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
             }
@@ -311,9 +276,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
 }
 
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st, int prec) {
-    if (FL != 1 && FL != 2 && FL != 3) return hipErrorInvalidValue;
-    if (prec && ((s.Cp & 127) || FL == 3)) return hipErrorInvalidValue;
-    if (FL == 3 && (!s.pair_ws || !s.pair_flag || (long)s.NB * stack_group_blocks(3, s.Cp, s.T) > 1024)) return hipErrorInvalidValue;
+    if (FL != 1 && FL != 2) return hipErrorInvalidValue;
+    if (prec && (s.Cp & 127)) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
     const int BN = stack_tile_frames(FL), MT = s.Cp >> 6, gsize = stack_group_blocks(FL, s.Cp, s.T);
     const size_t lds = prec ? stack3_lds_bytes(FL, s.taps, max_dil) : stack_lds_bytes(FL, s.taps, max_dil);
@@ -345,13 +309,12 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st,
         return hipGetLastError();
     }
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
-    else if (FL == 3) hipLaunchKernelGGL((stack_kernel<3>), grid, dim3(512), lds, st, b);
     else if (FL == 2 && s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2, 0>), grid, dim3(512), lds, st, b);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-int stack_tile_frames(int FL) { return FL == 2 ? 128 : 64; }
+int stack_tile_frames(int FL) { return 64 * FL; }
 // split-bf16 flavour: max over its two phase bodies (conv: S3 X tiles; 1x1: 128-channel S3 X tiles + the 64-frame h / skip tile)
 size_t stack3_lds_bytes(int FL, int taps, int max_dil) {
     return std::max(gemm_lds_bytes(FL, 1, taps, max_dil, 1, EPI_GATE), gemm_lds_bytes(1, 4, 1, 1, 1, EPI_RES_SKIP)) + 16;
@@ -359,20 +322,17 @@ size_t stack3_lds_bytes(int FL, int taps, int max_dil) {
 // blocks of one clip evaluation (= one barrier group): M tiles x frame tiles
 int stack_group_blocks(int FL, int Cp, int T) {
     const int BN = stack_tile_frames(FL);
-    if (FL == 3) return (Cp >> 6) * 2 * ((T + 127) / 128);      // pairs of 64-frame tiles
     return (Cp >> 6) * ((T + BN - 1) / BN);
 }
 // the conv's double-buffered X tiles + the resident h / skip tile
 size_t stack_lds_bytes(int FL, int taps, int max_dil) {
     const int BN = stack_tile_frames(FL), halo = ((taps - 1) / 2) * max_dil;
-    const int XBN = FL == 3 ? 128 : BN;                                           // frames of the conv's X tile
-    return (size_t)2 * 8 * (XBN + 2 * halo) * 16 + (size_t)32 * BN * 16 + 16;     // + one flag word (16-byte slot)
+    return (size_t)2 * 8 * (BN + 2 * halo) * 16 + (size_t)32 * BN * 16 + 16;     // + one flag word (16-byte slot)
 }
 
 hipError_t init_stack_kernels() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

@@ -77,9 +77,6 @@ def main():
         step()
         flag, ticks = eng.stack_status(128)
         print(f"xcd={xcd}: block 0 body ticks: last conv: K loop {ticks[64]}, body {ticks[65]}; a 1x1: K loop {ticks[96]}, body {ticks[97]}, first 2 steps done at {ticks[98]}, before RMW request {ticks[99]}")
-        if ticks[79] > ticks[64]:      # pair-split flavour: the mark behind the pair exchange (chunk marks 66..73 only: 8 chunks per block)
-            print(f"xcd={xcd}: pair-split conv: K loop {ticks[64]}, + exchange {ticks[79] - ticks[64]}, + epilogue {ticks[65] - ticks[79]} cycles")
-            ticks[79] = 0
         cs = [t for t in ticks[66:80] if t]            # chunk-start marks of block 0's last conv phase (first 14 chunks)
         if len(cs) > 1:
             print(f"xcd={xcd}: last conv phase, block 0: first chunk opens at {cs[0]}, chunk durations {[b - a for a, b in zip(cs[:-1], cs[1:])]}")
