@@ -39,7 +39,7 @@ VARIANTS = {
     # checker builds (tools/checked_build.sh), written next to the production library and selected with DR_LIB=<path>
     #   bounds: -DDR_BOUNDS - every hand-computed LDS address / in-range buffer offset of the kernels and every tensor
     #           extent of a launch is checked at run time (dr_debug_bounds reports)
-    #   asan:   the HOST side (engine.hip, comm.hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
+    #   asan:   the HOST side (pack / plan / abi / debug_abi / comm .hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
     #           UndefinedBehaviorSanitizer; device code is compiled as usual (-fno-gpu-sanitize)
     "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
     "ablate1": dict(flags=["-DDR_ABLATE=1", "-DDR_FOLD=0"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments

@@ -202,6 +202,11 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  * its workgroups are resident on the device at once; when something else holds CUs while it runs (a second engine,
  * stream or process computing on the same device) a group barrier can run into its spin bound - the launch then
  * carries on with wrong data, raises a flag, and every later fused launch of the engine returns immediately.
+ * (Since ABI 9 an engine avoids most of these by YIELDING first: engines of one process take turns on a per-device slot -
+ * the one that finds another engine's fused work still in flight switches to one launch per phase instead of waiting - and
+ * dr_create / dr_sample look for another PROCESS computing on the GPU in the kernel driver's process list
+ * (/sys/class/kfd/kfd/proc: csrc/tenants.h) and yield to it too, with one line on stderr.  The spin bound remains the
+ * backstop for what those checks cannot see: a tenant that arrives in the middle of a chain.)
  * dr_finish synchronises `stream` and checks that flag:
  *   DR_OK        everything issued on this engine since the last check is valid;
  *   DR_ETIMEOUT  it is NOT: recompute it.  The condition has been cleared and the engine switched to one launch per
@@ -211,8 +216,11 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  * gathered).  While an unchecked time-out is pending every entry point that COMPUTES (dr_forward, dr_forward_steps,
  * dr_step, dr_sample) refuses to start, and every entry point that CONSUMES a roll given an engine handle
  * (dr_note_runs, dr_frame_counts, dr_q_sample / dr_extract_x0, dr_gather) first does what dr_pending_timeout does -
- * it synchronises `stream` if fused launches have been issued since the last check - and returns DR_ETIMEOUT instead of
- * working on an invalid roll.  Only dr_finish (and dr_stack_status) clear the condition.
+ * it synchronises the stream the fused launches ran on (and `stream`) if any have been issued since the last check - and
+ * returns DR_ETIMEOUT instead of working on an invalid roll; dr_gather still takes part in the collective first (a time-out
+ * is a per-rank event: a rank that stayed out would leave its peers blocked) and reports DR_ETIMEOUT afterwards - the shard
+ * this rank contributed is invalid, every rank must gather again after it has been recomputed.  Only dr_finish (and
+ * dr_stack_status) clear the condition.
  */
 int dr_finish(dr_engine* e, void* stream);
 /* The check alone: DR_ETIMEOUT when a fused launch issued on this engine has timed out and dr_finish has not been called
