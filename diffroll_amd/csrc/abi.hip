@@ -63,14 +63,14 @@ int yield_fused(dr_engine* e, const char* why) {
                         "same results, no co-residency assumption)\n", why, e->cfg.device);
     return DR_OK;
 }
-// Another process on this GPU (tenants.h)?  Asked at creation and in front of every chain, at most every 20 ms (force:
-// now).  A first look that finds a second queue holder AND busy CUs may be seeing this engine's own front-end kernels: its
+// Another process on this GPU (tenants.h)?  Asked at creation and in front of a chain, at most every 250 ms (a scan is
+// ~0.1 ms of sysfs reads: 0.4 % of a single-clip chain if it ran every time; force: now - behind a graph capture).  A first look that finds a second queue holder AND busy CUs may be seeing this engine's own front-end kernels: its
 // stream is drained (only then - an exclusive GPU never pays for it) and the look repeated; true: yield.
 const char* kKfdRoot = "/sys/class/kfd/kfd";
 bool shared_with_another_process(dr_engine* e, hipStream_t st, bool force = false) {
     if (e->kfd_gpu_id < 0) return false;
     const double now = now_s();
-    if (!force && now - e->last_tenant_scan_s < 0.020) return false;
+    if (!force && now - e->last_tenant_scan_s < 0.250) return false;
     e->last_tenant_scan_s = now;
     TenantScan t = scan_tenants(kKfdRoot, e->kfd_gpu_id);
     if (!(t.readable && t.holders >= 2 && t.busy_cus > 0)) return false;

@@ -13,6 +13,7 @@
 // Host code; plain POSIX.
 #pragma once
 #include <dirent.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -77,6 +78,8 @@ inline TenantScan scan_tenants(const std::string& root, long gpu_id) {
     while (dirent* ent = readdir(d)) {
         if (ent->d_name[0] == '.') continue;
         const std::string pd = proc + "/" + ent->d_name;
+        // (a process that never opened this GPU has no stats_<gpu_id> directory: one syscall rules it out)
+        if (access((pd + "/stats_" + std::to_string(gpu_id)).c_str(), F_OK) != 0) continue;
         DIR* q = opendir((pd + "/queues").c_str());
         if (!q) continue;
         bool holds = false;
