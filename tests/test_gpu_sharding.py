@@ -281,3 +281,20 @@ def test_bench_exits_non_zero_when_the_group_is_smaller_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--config", "1"],
                        env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode != 0 and '"metric"' not in r.stdout
+
+
+def test_external_launcher_line_with_two_ranks_on_one_gpu():
+    """The driver's own launch line - python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ... - with
+    --share-gpu appended (both ranks on device 0): the ranks JOIN the launcher's group instead of spawning their own."""
+    import json
+    from diffroll_amd.launch import free_port
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--config", "1",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-split", "--no-roofline", "--no-cold-start"]
+    r = subprocess.run(cmd, env=_clean_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["dist"]["ranks_seen"] == 2 and j["dist"]["launcher"] == "torch.distributed.run"
+    assert len(j["per_rank_ms_per_step"]["all"]) == 2
