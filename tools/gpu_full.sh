@@ -5,7 +5,7 @@ O=gpurun_out/full
 mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 rm -f $O/margins.txt
-DR_PARITY_LOG=$PWD/$O/margins.txt timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -25 > $O/pytest.log
+DR_PARITY_LOG=$PWD/$O/margins.txt timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | grep -v "RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl path\|amdgpu.ids" | tail -25 > $O/pytest.log
 echo "pytest rc=$?" >> $O/pytest.log
 tail -6 $O/pytest.log
 sort -k2 -g -r $O/margins.txt | head -8

@@ -7,8 +7,9 @@ forced-mode run of the whole suite) do it here:
 
     DR_TEST_TUNE="fused_stack=0,tune.tile=3202" python -m pytest tests -m gpu
 
-`install()` applies those options to every engine the process creates and PINS them (later set_option calls on the
-same names - the facade re-asserting its `accumulation=` choice - are ignored).
+`install()` applies those options to every engine the process creates, as its DEFAULTS: a test that sets an option itself
+still gets what it asks for.  Two kinds are PINNED (later set_option calls on them are ignored): the process-wide `tune.*`
+knobs, and `blocked_accumulation`, which the facade re-asserts from its `accumulation=` keyword at every use.
 """
 import os
 
@@ -56,7 +57,7 @@ def install():
             orig_set(self, name, v)
 
     def set_option(self, name, value):
-        if name in _forced:
+        if name in _forced and (name.startswith("tune.") or name == "blocked_accumulation"):
             return
         orig_set(self, name, value)
 
