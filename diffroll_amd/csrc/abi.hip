@@ -190,11 +190,12 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
         return fail(nullptr, DR_EINVAL, "receptive halo (k-1)*dil = %d does not fit the 160 KiB LDS tile", rf);
     }
     g_engines[cfg->device].fetch_add(1);
-    {   // whose GPU is it?  (this process is idle on the device here: the zero vector's memset has been waited for)
+    {   // whose GPU is it?  (no device-wide synchronisation here: creating an engine must not wait for the chains other
+        // engines of the process have in flight - if THEY are what is busy, the second look still says so, and yielding is
+        // what this engine would do at its first launch anyway: the fused slot)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
             e->kfd_gpu_id = kfd_gpu_id(kKfdRoot, prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
-        (void)hipDeviceSynchronize();
         if (shared_with_another_process(e, nullptr)) (void)yield_fused(e, "another process is computing");
     }
     *out = e;
