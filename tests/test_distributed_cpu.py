@@ -134,3 +134,49 @@ def test_launch_helpers():
     assert launch.dist_info(None)["ranks_seen"] == 1
     p = launch.free_port()
     assert 1024 < p < 65536
+
+
+def test_scale_record_flags_a_cell_that_ran_with_fewer_ranks_than_asked(monkeypatch):
+    """tools/scale_table.py: the SCALE-shaped record marks share-gpu cells, computes efficiency against N = 1, and is NOT ok
+    (exit code 1) when a cell's process group had fewer ranks than the N it was asked for."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scale_table", os.path.join(root, "tools", "scale_table.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+
+    def cell(n, value, seen, share=False):
+        return {"value": value, "unit": "frames/s", "n_gpus": n, "ms_per_step": 1.0, "scaling": "weak", "_wall_s": 1.0,
+                "per_rank_ms_per_step": {"min": 1.0, "max": 1.1, "all": [1.0] * seen}, "gather_us": 3.0,
+                "dist": {"ranks_seen": seen, "backend": "nccl", "rccl_version": "2.26.6", "launcher": "x", "share_gpu": share},
+                "config": {"workload": "w"}}
+    table = {"config2/gpus1": cell(1, 100.0, 1), "config2/gpus2": cell(2, 190.0, 2, share=True),
+             "config2/gpus4": {"error": "4 GPUs requested but only 1 HIP device(s) visible"}}
+    rec = st.scale_record(table, [1, 2, 4], [2])
+    rows = rec["configs"]["2"]
+    assert rec["ok"] and rows[1]["efficiency_vs_n1"] == pytest.approx(0.95) and rows[1]["share_gpu"] is True
+    assert rows[2]["skipped"] and "only 1 HIP device" in rows[2]["reason"]
+    table["config2/gpus2"] = cell(2, 190.0, 1)            # asked for 2, the group had 1
+    rec = st.scale_record(table, [1, 2, 4], [2])
+    assert not rec["ok"] and "asked for 2 ranks" in rec["problems"][0]
+
+
+def test_share_gpu_mode_switches_the_group_to_gloo_and_host_tensors(monkeypatch):
+    from diffroll_amd import launch
+    monkeypatch.delenv("DR_BENCH_SHARE_GPU", raising=False)
+    assert not launch.share_gpu()
+    monkeypatch.setenv("DR_BENCH_SHARE_GPU", "1")
+    assert launch.share_gpu()
+    assert launch.collective_device(None, torch.device("cuda", 0)) == torch.device("cpu")
+
+    class _Gloo:
+        @staticmethod
+        def get_backend():
+            return "gloo"
+
+    class _Nccl(_Gloo):
+        @staticmethod
+        def get_backend():
+            return "nccl"
+    assert launch.collective_device(_Gloo, torch.device("cuda", 0)) == torch.device("cpu")
+    assert launch.collective_device(_Nccl, torch.device("cuda", 0)) == torch.device("cuda", 0)
