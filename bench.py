@@ -286,6 +286,11 @@ def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
     }
 
 
+def _modes():
+    from diffroll_amd import _cabi
+    return dict(_cabi.MODES)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,6 +316,9 @@ def main():
     args = ap.parse_args()
     if args.share_gpu:
         os.environ["DR_BENCH_SHARE_GPU"] = "1"
+    # A/B runs pin engine options for the process through DR_TEST_TUNE (tools/tuning_env.py); the line says so ("tuning")
+    from tools import tuning_env
+    forced_options = tuning_env.install()
 
     from diffroll_amd import launch
     if args.gpus < 1:
@@ -380,15 +388,37 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), o
 
+    fake_kfd = os.environ.get("DR_BENCH_FAKE_KFD")
+    if fake_kfd:
+        # test hook (tests/test_gpu_sharding.py): show the engine a KFD process list with a busy co-tenant that does not
+        # exist, so that it yields - and this script must then refuse to print a line
+        from diffroll_amd import _cabi
+        _cabi.load_library().dr_debug_kfd_root(fake_kfd.encode())
     for _ in range(args.warmup):
         one_step()
     fb0 = model.engine.fallbacks
     dt, out = timed(args.steps)
-    if model.engine.fallbacks != fb0:
-        # a fused launch timed out inside the timed region and was healed by re-running on the per-phase kernels:
-        # the rolls are right, but the time is not a measurement of the engine - fail the line instead of printing it
-        raise SystemExit(f"rank {rank}: a fused residual-stack launch timed out during the timed region (is something else "
-                         "using this GPU?): no benchmark line")
+    # What did the engine actually launch?  A fused launch that timed out and was healed (fallbacks), or an engine that
+    # YIELDED to per-phase launches because it believed the GPU shared (yields: at creation, in the warm-up or in the timed
+    # region), still returns the right rolls - but the time is then no measurement of the engine this line describes.  The
+    # verdict is collective (one rank's yield bends the max-over-ranks time of everybody): every rank learns it, no rank
+    # prints, every rank exits non-zero.  --share-gpu runs ask for per-phase launches themselves and are exempt.
+    st = model.engine.launch_state()
+    mine = torch.tensor([st["fallbacks"] - fb0, st["yields"], {v: k for k, v in _modes().items()}[st["mode"]]],
+                        device=cdev, dtype=torch.int64)
+    if dist is not None:
+        allst = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allst, mine)
+        states = [[int(v) for v in t.tolist()] for t in allst]
+    else:
+        states = [[int(v) for v in mine.tolist()]]
+    modes = [_modes()[sx[2]] for sx in states]
+    if not launch.share_gpu():
+        bad = [(r, sx) for r, sx in enumerate(states) if sx[0] or sx[1]]
+        if bad:
+            raise SystemExit(f"rank {rank}: no benchmark line - " + "; ".join(
+                f"rank {r}: {sx[0]} fused time-out(s) in the timed region, {sx[1]} yield(s) to per-phase launches" for r, sx in bad) +
+                " (is something else using the GPU(s)?  see dr_launch_state / csrc/tenants.h)")
 
     frames = world * B * T * args.steps
     result = {
@@ -404,8 +434,13 @@ def main():
                    "inpainting_t": inp_t, "parallelism": f"batch-shard x{world}", "graph": True,
                    "conv_accumulation": "blocked" if args.accumulation == "auto" else args.accumulation},
         "dist": launch.dist_info(dist),
-        "fused_fallbacks": 0,
+        # per rank: fused time-outs healed inside the timed region / yields since engine creation (both 0 or there is no
+        # line, except under --share-gpu) and how the residual layers were launched (dr_launch_state)
+        "fused_fallbacks": sum(sx[0] for sx in states), "fused_yields": sum(sx[1] for sx in states),
+        "launch_mode": modes[0] if len(set(modes)) == 1 else "mixed", "per_rank_launch_mode": modes,
     }
+    if forced_options:
+        result["tuning"] = dict(forced_options)      # NOT the shipping configuration: an A/B run
     # straggler visibility for the scaling table: every rank's own time over the same K steps (no barrier inside),
     # and the final all-gather on its own (HIP events around 10 back-to-back gathers of the finished rolls)
     t0 = time.perf_counter()

@@ -1,4 +1,5 @@
-"""ctypes binding of the C-ABI in include/diffroll_amd.h (the only way Python reaches the kernels).
+"""ctypes binding of the C-ABI: include/diffroll_amd.h (the boundary) and include/diffroll_amd_debug.h (measurement /
+checker / test entry points of the same library) - the only way Python reaches the kernels.
 
 There is deliberately no fallback: if the shared library is missing or no MI355X is visible the
 calls raise - a silent CPU path would void every parity and performance claim.
@@ -11,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DR_LIB") or os.path.join(_HERE, "lib", "libdiffroll_amd.so")   # DR_LIB: measurement builds
 
-DR_ABI_VERSION = 9
+DR_ABI_VERSION = 10
 DR_OK, DR_EINVAL, DR_ESTATE, DR_EHIP, DR_ENOMEM, DR_ENAME, DR_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6
 
 SAMPLERS = {
@@ -29,17 +30,23 @@ COND_SPEC, COND_UNCOND = 0, 1
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 NORM_MODES = {"imagewise": 0, "framewise": 1}
 
-# every symbol include/diffroll_amd.h declares
+# every symbol include/diffroll_amd.h declares (the boundary) ...
 EXPORTS = [
-    "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables",
-    "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_frame_counts", "dr_note_runs", "dr_q_sample",
-    "dr_extract_x0", "dr_set_spec_norm", "dr_set_precision", "dr_profile_enable",
-    "dr_profile_read", "dr_bench_layer", "dr_bench_pointwise", "dr_debug_ticks",
-    "dr_profile_read_ex", "dr_set_option", "dr_stack_status", "dr_set_frontend_tables",
-    "dr_rccl_version", "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error",
-    "dr_gather", "dr_finish", "dr_sample_checked", "dr_stack_fallbacks", "dr_debug_stft_power", "dr_debug_bounds", "dr_tail_launches",
-    "dr_pending_timeout", "dr_cold_times", "dr_debug_tenants",
+    "dr_abi_version", "dr_create", "dr_destroy", "dr_last_error", "dr_set_param", "dr_set_tables", "dr_set_frontend_tables",
+    "dr_commit", "dr_frontend", "dr_forward", "dr_forward_steps", "dr_step", "dr_sample", "dr_sample_checked", "dr_finish",
+    "dr_pending_timeout", "dr_launch_state", "dr_note_runs", "dr_frame_counts", "dr_q_sample", "dr_extract_x0",
+    "dr_set_spec_norm", "dr_set_precision", "dr_set_option",
+    "dr_comm_unique_id", "dr_comm_create", "dr_comm_destroy", "dr_comm_info", "dr_comm_last_error", "dr_gather",
 ]
+# ... and every symbol of include/diffroll_amd_debug.h (the lab)
+DEBUG_EXPORTS = [
+    "dr_debug_stft_power", "dr_debug_bounds", "dr_debug_tenants", "dr_debug_kfd_root", "dr_debug_set_option", "dr_debug_ticks",
+    "dr_stack_status", "dr_cold_times", "dr_profile_enable", "dr_profile_read", "dr_profile_read_ex",
+    "dr_bench_layer", "dr_bench_pointwise",
+]
+# the options dr_set_option knows; every other name goes to dr_debug_set_option (Engine.set_option)
+PUBLIC_OPTIONS = ("blocked_accumulation", "fused_rearm", "fused_stack", "fused_tail")
+MODES = {0: "none", 1: "per_phase", 2: "fused_stack", 3: "fused_stack+tail"}
 
 
 class DrConfig(C.Structure):
@@ -51,6 +58,11 @@ class DrConfig(C.Structure):
         ("n_fft", C.c_int32), ("hop_length", C.c_int32),
         ("f_min", C.c_float), ("f_max", C.c_float), ("beta_start", C.c_float), ("beta_end", C.c_float),
     ]
+
+
+class DrLaunchInfo(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("fused_enabled", C.c_int32), ("fallbacks", C.c_int64), ("yields", C.c_int64),
+                ("rearms", C.c_int64), ("stack_launches", C.c_int64), ("tail_launches", C.c_int64)]
 
 
 _lib = None
@@ -108,10 +120,8 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_sample_checked.restype = C.c_int
     lib.dr_sample_checked.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int,
                                       C.POINTER(C.c_int32), vp]
-    lib.dr_stack_fallbacks.restype = C.c_int
-    lib.dr_stack_fallbacks.argtypes = [vp, C.POINTER(C.c_int64)]
-    lib.dr_tail_launches.restype = C.c_int
-    lib.dr_tail_launches.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.dr_launch_state.restype = C.c_int
+    lib.dr_launch_state.argtypes = [vp, C.POINTER(DrLaunchInfo)]
     lib.dr_pending_timeout.restype = C.c_int
     lib.dr_pending_timeout.argtypes = [vp, vp]
     lib.dr_cold_times.restype = C.c_int
@@ -129,6 +139,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_debug_bounds.argtypes = [C.POINTER(C.c_int64), C.c_int]
     lib.dr_debug_tenants.restype = C.c_int
     lib.dr_debug_tenants.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    lib.dr_debug_kfd_root.restype = C.c_int
+    lib.dr_debug_kfd_root.argtypes = [C.c_char_p]
+    lib.dr_debug_set_option.restype = C.c_int
+    lib.dr_debug_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     lib.dr_set_spec_norm.restype = C.c_int
     lib.dr_set_spec_norm.argtypes = [vp, C.c_int]
     lib.dr_set_precision.restype = C.c_int
@@ -150,8 +164,6 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_bench_pointwise.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.dr_debug_ticks.restype = C.c_int
     lib.dr_debug_ticks.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    lib.dr_rccl_version.restype = C.c_int
-    lib.dr_rccl_version.argtypes = [C.POINTER(C.c_int)]
     lib.dr_comm_unique_id.restype = C.c_int
     lib.dr_comm_unique_id.argtypes = [C.c_char_p]
     lib.dr_comm_create.restype = C.c_int
@@ -159,7 +171,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     lib.dr_comm_destroy.restype = None
     lib.dr_comm_destroy.argtypes = [vp]
     lib.dr_comm_info.restype = C.c_int
-    lib.dr_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.dr_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.dr_comm_last_error.restype = C.c_char_p
     lib.dr_comm_last_error.argtypes = []
     lib.dr_gather.restype = C.c_int

@@ -16,8 +16,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdiffroll_amd.so")
 # one translation unit per kernel family (a kernel edit rebuilds its unit only; the units compile in parallel)
 SOURCES = ["gemm.hip", "stack.hip", "tail.hip", "update.hip", "frontend.hip", "pack.hip", "plan.hip", "abi.hip", "debug_abi.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "device_common.h", "gemm_body.h", "persistent.h", "update_quad.h", "engine_state.h")] + \
-          [os.path.join(os.path.dirname(HERE), "include", "diffroll_amd.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("kernels.h", "device_common.h", "gemm_body.h", "persistent.h", "update_quad.h", "engine_state.h", "tenants.h")] + \
+          [os.path.join(os.path.dirname(HERE), "include", h) for h in ("diffroll_amd.h", "diffroll_amd_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -47,6 +47,9 @@ VARIANTS = {
     # A/B builds of the conv K loop (round 4): the rounds 1-3 loop (one chain per output, two weight-fragment sets) /
     # blocked accumulation off, in-place fragments on / blocked accumulation with two fragment sets
     # litmus builds (WRONG on purpose): the hand-over without its vmcnt wait / hand-offs without write-through stores
+    # test build of the time-out path: the ONLY library that knows the option "stack_fault_test" (the persistent kernels' group
+    # barriers can be told to wait for one arrival too many); correct results otherwise.  tests/hook_cases.py runs against it
+    "hook": dict(flags=["-DDR_FAULT_HOOK"], link=[]),
     "fault1": dict(flags=["-DDR_FAULT=1"], link=[]),
     "fault2": dict(flags=["-DDR_FAULT=2"], link=[]),
     "r3loop": dict(flags=["-DDR_FOLD=0", "-DDR_AINPLACE=0"], link=[]),
@@ -77,6 +80,13 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     objs = []
     relink = force
     jobs = []
+    # objects of translation units that no longer exist (or clang-offload-bundler leftovers of an interrupted build) must not
+    # linger next to the ones the library is linked from
+    wanted = {src.replace(".hip", ".o") for src in SOURCES}
+    for name in os.listdir(objdir):
+        if name not in wanted:
+            os.remove(os.path.join(objdir, name))
+            relink = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))

@@ -4,8 +4,9 @@
 ``torch.save({'state_dict': ..., 'hyper_parameters': ...})``.  In the reference's checkpoints the
 hyper-parameters contain OmegaConf containers (``spec_args``, ``sampling``, ``training``, ...: Hydra config
 nodes passed straight into the constructor), so plain ``torch.load`` needs ``omegaconf`` (and friends)
-importable.  Neither is a dependency here: unknown classes are unpickled into inert stand-ins that only
-record their state, and OmegaConf containers are then converted to plain dict / list / scalars.
+importable.  Neither is a dependency here, and NOTHING the file names is trusted: apart from an allow-list of tensor /
+container / scalar constructors every global of the pickle stream is unpickled into an inert stand-in that only records
+its state (never imported, never called), and OmegaConf containers are then converted to plain dict / list / scalars.
 
 The converter knows the pickled shape of OmegaConf 2.x nodes (containers keep their children in
 ``_content``, value nodes their payload in ``_val``); and resolves
@@ -45,12 +46,41 @@ def _make_stub(module: str, name: str):
     return type(name, (_Stub,), {"_dr_module": module, "_dr_name": name})
 
 
+# What a checkpoint's pickle stream may IMPORT: the constructors of tensors, containers and scalars - nothing else.  Every
+# other global the stream names (pytorch_lightning / omegaconf classes, but equally os.system, builtins.eval, ...) becomes an
+# inert stand-in that records its arguments: it is never imported, never called.
+_SAFE_BUILTINS = {"dict", "list", "tuple", "set", "frozenset", "int", "float", "bool", "str", "bytes", "bytearray", "complex",
+                  "slice", "range"}
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"),
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("numpy.core.multiarray", "scalar"), ("numpy.core.multiarray", "_reconstruct"),
+    ("numpy._core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+    ("_codecs", "encode"),
+}
+
+
+def _allowed(module: str, name: str) -> bool:
+    if (module, name) in _SAFE_GLOBALS:
+        return True
+    if module == "builtins" and name in _SAFE_BUILTINS:
+        return True
+    if module == "torch" and name.isidentifier() and isinstance(getattr(torch, name, None), torch.dtype):
+        return True                                     # torch.float32, ... (a dtype pickles as a global of that name)
+    return False
+
+
 class TolerantUnpickler(pickle.Unpickler):
+    """Allow-listed globals are imported; everything else unpickles into an inert stand-in (nothing of the checkpoint's
+    packages - or of anybody's - is imported or executed)."""
+
     def find_class(self, module, name):
-        try:
+        if _allowed(module, name):
             return super().find_class(module, name)
-        except (ImportError, AttributeError):
-            return _make_stub(module, name)
+        return _make_stub(module, name)
 
 
 class _TolerantPickle:
@@ -169,16 +199,29 @@ def to_plain(obj: Any, _depth: int = 0) -> Any:
     return obj
 
 
-def load_checkpoint(path: str) -> Dict[str, Any]:
-    """-> {'state_dict': {name: tensor}, 'hyper_parameters': plain dict} (other entries are dropped)."""
-    try:
+def load_checkpoint(path: str, trust: bool = False) -> Dict[str, Any]:
+    """-> {'state_dict': {name: tensor}, 'hyper_parameters': plain dict} (other entries are dropped).
+
+    Safe by default: first ``torch.load(weights_only=True)``; a file that needs more than that (every Lightning checkpoint
+    with OmegaConf hyper-parameters does) is read by an allow-listing unpickler - tensor / container / scalar
+    constructors are imported, EVERY other global the pickle names becomes an inert stand-in: a checkpoint that names
+    ``os.system`` loads to a stub and executes nothing.  ``trust=True`` opts into the full unpickle (what Lightning's own
+    ``load_from_checkpoint``, sampling.py:54, does): only for files from sources you would run code from."""
+    if trust:
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
-    except Exception:
-        ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
+    else:
+        try:
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:       # noqa: BLE001 - whatever the strict loader rejects goes through the allow-list
+            ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
     if not isinstance(ckpt, dict) or "state_dict" not in ckpt:
         raise ValueError(f"{path}: not a Lightning checkpoint (no 'state_dict')")
-    return {"state_dict": dict(ckpt["state_dict"]),
-            "hyper_parameters": to_plain(ckpt.get("hyper_parameters", {})) or {}}
+    sd = ckpt["state_dict"]
+    bad = [k for k, v in sd.items() if not torch.is_tensor(v)] if isinstance(sd, dict) else ["state_dict"]
+    if bad:
+        raise ValueError(f"{path}: state_dict entries that are not tensors ({bad[:3]}): refused "
+                         "(pass trust=True to unpickle the file as Lightning would)")
+    return {"state_dict": dict(sd), "hyper_parameters": to_plain(ckpt.get("hyper_parameters", {})) or {}}
 
 
 def constructor_kwargs(cls, hyper_parameters: Dict[str, Any], overrides: Dict[str, Any]) -> Dict[str, Any]:

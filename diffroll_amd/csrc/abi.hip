@@ -1,8 +1,9 @@
-// Host side, part 3: the C-ABI of include/diffroll_amd.h - engine life cycle, front-end, forward / step / sample (the
-// reverse chain as one hipGraph), time-out handling of the persistent kernels, the consumers of a finished roll, options.
+// Host side, part 3: the C-ABI of include/diffroll_amd.h (the boundary) - engine life cycle, front-end, forward / step / sample
+// (the reverse chain as one hipGraph), time-out handling of the persistent kernels, the consumers of a finished roll, options.
 #include "engine_state.h"
 #include "tenants.h"
 
+#include <condition_variable>
 #include <mutex>
 
 namespace drh {
@@ -12,25 +13,30 @@ void release_stager(int dev);       // pack.hip
 std::atomic<int> g_engines[MAX_DEVICES];      // live engines per device: the last one out releases the upload stager
 
 // The persistent kernels assume that all their workgroups are resident at once - true while ONE engine computes on the
-// device.  Engines of one process take turns on a per-device "fused slot": an engine that wants to issue fused launches
-// while another engine's last fused work has not finished (event query, no synchronisation) does not wait and does not
-// gamble on the spin bound - it YIELDS: from then on it runs one launch per phase (fused_stack = 0: bit-identical
-// results, no residency assumption), which co-exists with the other engine's persistent launches.  (Other PROCESSES on
-// the device are looked for in tenants.h; the ~1 s spin bound of the barriers stays as the backstop for everything else.)
+// device.  Engines of one process take turns on a per-device "fused slot".  An engine that wants to issue fused launches
+// while another engine of the process is issuing its own (another host thread, inside an API call) waits for that call to
+// return - microseconds to milliseconds of launch overhead, no GPU wait; if that engine's last fused work is still running
+// on the device, the newcomer's stream is made to wait for it ON THE DEVICE (hipStreamWaitEvent on the event recorded
+// behind that work): the two engines' persistent launches then never overlap, nobody synchronises the host and nobody gives
+// up fusing.  (Until round 5 the newcomer yielded to per-phase launches for the rest of its life instead; its per-phase
+// blocks cannot co-reside with a persistent launch that owns every CU's LDS either, so nothing was gained by not waiting.)
+// (Other PROCESSES on the device are looked for in tenants.h; the ~1 s spin bound of the barriers stays as the backstop.)
 struct FusedSlot {
     std::mutex mu;
+    std::condition_variable cv;
     dr_engine* owner = nullptr;
     bool claimed = false;          // the owner is issuing launches right now (its event is not recorded yet)
     hipEvent_t done = nullptr;     // recorded behind the owner's last fused work
 };
 FusedSlot g_slots[MAX_DEVICES];
 
-bool claim_fused_slot(dr_engine* e) {
+// true: the slot is ours (after `st` has been ordered behind the previous owner's fused work, if any is in flight)
+bool claim_fused_slot(dr_engine* e, hipStream_t st) {
     FusedSlot& s = g_slots[e->cfg.device];
-    std::lock_guard<std::mutex> lk(s.mu);
-    if (s.owner && s.owner != e) {
-        if (s.claimed) return false;
-        if (s.done && hipEventQuery(s.done) == hipErrorNotReady) return false;
+    std::unique_lock<std::mutex> lk(s.mu);
+    s.cv.wait(lk, [&] { return !s.claimed || s.owner == e; });
+    if (s.owner && s.owner != e && s.done && hipEventQuery(s.done) == hipErrorNotReady) {
+        if (hipStreamWaitEvent(st, s.done, 0) != hipSuccess) return false;
     }
     s.owner = e;
     s.claimed = true;
@@ -38,46 +44,62 @@ bool claim_fused_slot(dr_engine* e) {
 }
 void release_fused_slot(dr_engine* e, hipStream_t st) {
     FusedSlot& s = g_slots[e->cfg.device];
-    std::lock_guard<std::mutex> lk(s.mu);
-    if (s.owner != e) return;
-    if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) s.done = nullptr;
-    if (s.done) (void)hipEventRecord(s.done, st);
-    s.claimed = false;
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (s.owner != e) return;
+        if (!s.done && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) s.done = nullptr;
+        if (s.done) (void)hipEventRecord(s.done, st);
+        s.claimed = false;
+    }
+    s.cv.notify_all();
 }
 void forget_fused_slot(dr_engine* e) {
     FusedSlot& s = g_slots[e->cfg.device];
-    std::lock_guard<std::mutex> lk(s.mu);
-    if (s.owner == e) { s.owner = nullptr; s.claimed = false; }
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        if (s.owner == e) { s.owner = nullptr; s.claimed = false; }
+    }
+    s.cv.notify_all();
 }
-// this engine stops fusing (the device is shared): per-phase launches from the next launch on
+// this engine stops fusing (another process is computing on the device): per-phase launches from the next launch on
 int yield_fused(dr_engine* e, const char* why) {
     if (e->gexec && e->graph_stream_set) HIPCHK(e, hipStreamSynchronize(e->graph_stream));      // its captured chain may still be running
     drop_graph(e);
-    e->healed_from = e->opt_stack;      // (option "fused_rearm" may restore it after clean chains)
-    e->clean_chains = 0;
+    e->yielded_from = e->opt_stack;     // (restored by dr_sample after two clean looks)
+    e->yield_clean = 0;
     e->opt_stack = 0;
     e->stack_yields += 1;
-    static std::atomic<bool> said{false};
-    if (!said.exchange(true))
-        fprintf(stderr, "[diffroll_amd] %s on device %d: this engine uses one launch per phase from now on (option fused_stack = 0: "
-                        "same results, no co-residency assumption)\n", why, e->cfg.device);
+    if (e->stack_yields <= 3)           // per engine (a measurement reads the counter: dr_launch_state); not a log flood
+        fprintf(stderr, "[diffroll_amd] engine %p: %s on device %d - one launch per phase from now on (same results, no co-residency "
+                        "assumption; yield #%lld of this engine; fused launches come back after two clean looks)\n",
+                (void*)e, why, e->cfg.device, (long long)e->stack_yields);
     return DR_OK;
 }
 // Another process on this GPU (tenants.h)?  Asked at creation and in front of a chain, at most every 250 ms (a scan is
-// ~0.1 ms of sysfs reads: 0.4 % of a single-clip chain if it ran every time; force: now - behind a graph capture).  A first look that finds a second queue holder AND busy CUs may be seeing this engine's own front-end kernels: its
-// stream is drained (only then - an exclusive GPU never pays for it) and the look repeated; true: yield.
-const char* kKfdRoot = "/sys/class/kfd/kfd";
-bool shared_with_another_process(dr_engine* e, hipStream_t st, bool force = false) {
-    if (e->kfd_gpu_id < 0) return false;
+// ~0.1 ms of sysfs reads: 0.4 % of a single-clip chain if it ran every time; force: now - behind a graph capture).
+// Returns 1 = yes, 0 = no, -1 = not looked (rate limit / no sysfs / undecided).  A first look that finds a second queue
+// holder AND busy CUs may be seeing THIS process's own kernels - the engine's front-end, another stream of the caller, the
+// previous sample's RCCL all-gather on the communicator's stream (a rank of a multi-GPU job never waits for that before it
+// starts its next sample): only then - an exclusive GPU never pays for it - everything this process has in flight on
+// the device is waited for (hipDeviceSynchronize: microseconds of front-end work in practice) and the look repeated, so
+// that what is still busy afterwards is somebody else's.
+std::mutex g_kfd_mu;
+std::string g_kfd_root = "/sys/class/kfd/kfd";
+std::string kfd_root() { std::lock_guard<std::mutex> lk(g_kfd_mu); return g_kfd_root; }
+void set_kfd_root(const char* root) { std::lock_guard<std::mutex> lk(g_kfd_mu); g_kfd_root = root ? root : "/sys/class/kfd/kfd"; }
+int shared_with_another_process(dr_engine* e, bool force = false, bool may_sync = true) {
+    if (e->kfd_gpu_id < 0) return -1;
     const double now = now_s();
-    if (!force && now - e->last_tenant_scan_s < 0.250) return false;
+    if (!force && now - e->last_tenant_scan_s < 0.250) return -1;
     e->last_tenant_scan_s = now;
-    TenantScan t = scan_tenants(kKfdRoot, e->kfd_gpu_id);
-    if (!(t.readable && t.holders >= 2 && t.busy_cus > 0)) return false;
-    (void)hipStreamSynchronize(st);
-    if (e->unverified && e->fused_stream != st) (void)hipStreamSynchronize(e->fused_stream);
-    t = scan_tenants(kKfdRoot, e->kfd_gpu_id);
-    return t.holders >= 2 && t.busy_cus > 0;
+    const std::string root = kfd_root();
+    TenantScan t = scan_tenants(root, e->kfd_gpu_id);
+    if (!t.readable) return -1;
+    if (!(t.holders >= 2 && t.busy_cus > 0)) return 0;
+    if (!may_sync) return -1;           // (undecided: what is busy may be this process's own other engines)
+    (void)hipDeviceSynchronize();
+    t = scan_tenants(root, e->kfd_gpu_id);
+    return (t.holders >= 2 && t.busy_cus > 0) ? 1 : 0;
 }
 
 // the engine's turn on the slot for the duration of one API call that may issue fused launches
@@ -88,8 +110,8 @@ struct FusedTurn {
     int rc = DR_OK;
     FusedTurn(dr_engine* e_, hipStream_t st_) : e(e_), st(st_) {
         if (!e->opt_stack) return;
-        if (claim_fused_slot(e)) held = true;
-        else rc = yield_fused(e, "another engine of this process is computing");
+        if (claim_fused_slot(e, st)) held = true;
+        else rc = fail(e, DR_EHIP, "hipStreamWaitEvent behind another engine's fused work failed");
     }
     ~FusedTurn() { if (held) release_fused_slot(e, st); }
     FusedTurn(const FusedTurn&) = delete;
@@ -121,6 +143,58 @@ int check_ready(dr_engine* e, int sampler, int B, int T) {
         return fail(e, DR_ESTATE, "dr_frontend(B=%d,T=%d) must precede a conditional evaluation with B=%d,T=%d",
                     e->fe_B, e->fe_T, B, T);
     return DR_OK;
+}
+
+// dr_set_option (lab = false: the product's options) / dr_debug_set_option (lab = true: the A/B and test knobs too)
+int set_option(dr_engine* e, const char* name, int value, bool lab) {
+    if (!e || !name) return fail(e, DR_EINVAL, "null argument");
+    const std::string n = name;
+    DeviceGuard guard(e->cfg.device);
+    auto drop = [&]() {
+        (void)hipDeviceSynchronize();
+        drop_graph(e);
+    };
+    if (n == "fused_stack") {
+        if (e->opt_stack != value) drop();
+        e->opt_stack = value;
+        e->yielded_from = 0; e->healed_from = 0;      // the caller's word replaces any pending re-arm
+        return DR_OK;
+    }
+    if (n == "fused_rearm") { e->opt_rearm = value; return DR_OK; }
+    if (n == "blocked_accumulation") {
+        if (value != 1 && value != 2) return fail(e, DR_EINVAL, "blocked_accumulation is 1 or 2");
+        if (e->opt_blocked != value) drop();
+        e->opt_blocked = value;
+        return DR_OK;
+    }
+    if (n == "fused_tail") { if (e->opt_tail != value) drop(); e->opt_tail = value; return DR_OK; }
+    if (!lab) return fail(e, DR_ENAME, "unknown option '%s'", name);
+    if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop(); e->opt_stack_xcd = value; return DR_OK; }
+    if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop(); e->opt_stack_warm = value; return DR_OK; }
+#ifdef DR_FAULT_HOOK
+    if (n == "stack_fault_test") { if (e->opt_stack_fault != value) drop(); e->opt_stack_fault = value; return DR_OK; }
+#endif
+    if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop(); e->stack_dbg_on = value; return DR_OK; }
+    if (n.compare(0, 5, "tune.") == 0) {      // A/B knobs of planners and launchers: PROCESS-wide (kernels.h: Tuning)
+        Tuning& t = tuning();
+        const std::string f = n.substr(5);
+        if (f == "ksplit_blocks") {
+            if (t.ksplit_blocks.load() != value) { t.ksplit_blocks.store(value); tuning_epoch().fetch_add(1); drop(); }
+            return DR_OK;
+        }
+        std::atomic<int>* field = f == "pack_threads" ? &t.pack_threads : f == "tile" ? &t.tile : f == "pw" ? &t.pw : f == "pw_nw" ? &t.pw_nw
+                   : f == "pwk" ? &t.pwk : f == "ksplit_max" ? &t.ksplit_max : f == "one_ks" ? &t.one_ks : f == "stack3" ? &t.stack3
+                   : f == "stack_fl" ? &t.stack_fl : f == "tail_t4" ? &t.tail_t4 : f == "xcd_n" ? &t.xcd_n : f == "xcd_model" ? &t.xcd_model
+                   : f == "s3_eager" ? &t.s3_eager : f == "debug_chunks" ? &t.debug_chunks : nullptr;
+        if (!field) return fail(e, DR_ENAME, "unknown option '%s'", name);
+        if (field->load() != value) {
+            field->store(value);
+            tuning_epoch().fetch_add(1);      // every engine drops its captured chain at its next dr_sample
+            drop();
+        }
+        return DR_OK;
+    }
+    return fail(e, DR_ENAME, "unknown option '%s'", name);
 }
 
 }  // namespace drh
@@ -190,13 +264,14 @@ int dr_create(dr_engine** out, const dr_config* cfg) {
         return fail(nullptr, DR_EINVAL, "receptive halo (k-1)*dil = %d does not fit the 160 KiB LDS tile", rf);
     }
     g_engines[cfg->device].fetch_add(1);
-    {   // whose GPU is it?  (no device-wide synchronisation here: creating an engine must not wait for the chains other
-        // engines of the process have in flight - if THEY are what is busy, the second look still says so, and yielding is
-        // what this engine would do at its first launch anyway: the fused slot)
+    {   // whose GPU is it?
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess)
-            e->kfd_gpu_id = kfd_gpu_id(kKfdRoot, prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
-        if (shared_with_another_process(e, nullptr)) (void)yield_fused(e, "another process is computing");
+            e->kfd_gpu_id = kfd_gpu_id(kfd_root(), prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
+        // (only the FIRST engine of the process on this device may wait for the device in a doubtful look: later ones would
+        // wait for their siblings' chains - and if those are what is busy, the fused slot already handles it)
+        if (shared_with_another_process(e, false, g_engines[cfg->device].load() == 1) == 1)
+            (void)yield_fused(e, "another process is computing");
     }
     *out = e;
     return DR_OK;
@@ -418,9 +493,28 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
     if (sampler_shape(sampler, B, NB, n_cond)) return fail(e, DR_EINVAL, "unknown sampler %d", sampler);
     if ((rc = ensure_workspace(e, NB, T))) return rc;
     hipStream_t st = (hipStream_t)stream;
-    // (engine idle = everything it issued has been consumed through dr_finish: what is busy on the GPU now is not ours)
-    if (e->opt_stack && shared_with_another_process(e, st)) {
-        if ((rc = yield_fused(e, "another process is computing"))) return rc;
+    if (e->tuning_epoch != tuning_epoch().load()) {      // a tune.* knob changed (any engine, any thread): the cached chain is stale
+        if (e->gexec && e->graph_stream_set) HIPCHK(e, hipStreamSynchronize(e->graph_stream));
+        drop_graph(e);
+        e->tuning_epoch = tuning_epoch().load();
+    }
+    if (e->opt_stack) {
+        if (shared_with_another_process(e) == 1 && (rc = yield_fused(e, "another process is computing"))) return rc;
+    } else if (e->yielded_from) {
+        // a yield is a precaution, not a verdict: two looks in a row (>= 250 ms apart, in front of later chains) that find
+        // the GPU exclusive again switch the fused launches back on
+        const int shared = shared_with_another_process(e);
+        if (shared == 1) e->yield_clean = 0;
+        else if (shared == 0 && ++e->yield_clean >= 2) {
+            if (e->gexec && e->graph_stream_set) HIPCHK(e, hipStreamSynchronize(e->graph_stream));
+            drop_graph(e);
+            e->opt_stack = e->yielded_from;
+            e->yielded_from = 0;
+            e->yield_clean = 0;
+            e->stack_rearms += 1;
+            if (e->stack_rearms <= 3)
+                fprintf(stderr, "[diffroll_amd] engine %p: device %d is this process's own again - fused launches back on\n", (void*)e, e->cfg.device);
+        }
     }
     FusedTurn turn(e, st);      // (released - event recorded on `st` - when this call returns, behind the chain's launches)
     if (turn.rc) return turn.rc;
@@ -478,9 +572,10 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
         HIPCHK(e, hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0));
         e->t_capture_s = now_s() - tc0;
         e->gkey = key;
+        e->tuning_epoch = tuning_epoch().load();
         // capture + instantiation took tens of milliseconds: look again before a chain of persistent launches goes out
         if (attempt == 0 && e->opt_stack && turn.held) {
-            if (shared_with_another_process(e, st, true)) {
+            if (shared_with_another_process(e, true) == 1) {
                 if ((rc = yield_fused(e, "another process is computing"))) return rc;      // (drops the graph: captured again, per phase)
             }
         }
@@ -515,8 +610,10 @@ int dr_finish(dr_engine* e, void* stream) {
     drop_graph(e);
     e->unverified = false;
     if (e->opt_stack) e->healed_from = e->opt_stack;      // (option "fused_rearm" may restore it after clean chains)
+    else if (e->yielded_from) e->healed_from = e->yielded_from;
     e->clean_chains = 0;
     e->opt_stack = 0;
+    e->yielded_from = 0;                                  // (a time-out outranks a pending yield: only fused_rearm re-arms now)
     e->stack_fallbacks += 1;
     static std::atomic<bool> warned{false};           // (engines of several host threads may get here together)
     if (!warned.exchange(true)) {
@@ -559,6 +656,7 @@ int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_nois
         e->opt_stack = e->healed_from;
         e->healed_from = 0;
         e->clean_chains = 0;
+        e->stack_rearms += 1;
     }
     if (rc != DR_ETIMEOUT) return rc;
     if (!may_fuse) return rc;         // cannot happen: no fused launch was issued
@@ -588,24 +686,15 @@ int dr_pending_timeout(dr_engine* e, void* stream) {
     return DR_OK;
 }
 
-int dr_cold_times(dr_engine* e, double* out5) {
-    if (!e || !out5) return DR_EINVAL;
-    out5[0] = e->t_pack_s; out5[1] = e->t_upload_s; out5[2] = e->t_tables_s; out5[3] = e->t_capture_s;
-    size_t nodes = 0;
-    if (e->graph && hipGraphGetNodes(e->graph, nullptr, &nodes) != hipSuccess) nodes = 0;
-    out5[4] = (double)nodes;
-    return DR_OK;
-}
-
-int dr_stack_fallbacks(dr_engine* e, int64_t* count) {
-    if (!e || !count) return DR_EINVAL;
-    *count = e->stack_fallbacks;
-    return DR_OK;
-}
-
-int dr_tail_launches(dr_engine* e, int64_t* count) {
-    if (!e || !count) return DR_EINVAL;
-    *count = e->tail_launches;
+int dr_launch_state(dr_engine* e, dr_launch_info* out) {
+    if (!e || !out) return DR_EINVAL;
+    out->mode = e->last_mode;
+    out->fused_enabled = e->opt_stack;
+    out->fallbacks = e->stack_fallbacks;
+    out->yields = e->stack_yields;
+    out->rearms = e->stack_rearms;
+    out->stack_launches = e->stack_launches;
+    out->tail_launches = e->tail_launches;
     return DR_OK;
 }
 
@@ -657,64 +746,7 @@ int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, cons
     return noise_mix(e, 1, d_x_t, d_epsilon, d_t, d_sac, d_s1m, n_steps, B, per_sample, d_out, stream);
 }
 
-int dr_set_option(dr_engine* e, const char* name, int value) {
-    if (!e || !name) return fail(e, DR_EINVAL, "null argument");
-    const std::string n = name;
-    DeviceGuard guard(e->cfg.device);
-    auto drop_graph = [&]() {
-        (void)hipDeviceSynchronize();
-        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
-        if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
-        e->gkey = GraphKey{};
-    };
-    if (n == "fused_stack") { if (e->opt_stack != value) drop_graph(); e->opt_stack = value; return DR_OK; }
-    if (n == "fused_stack_xcd") { if (e->opt_stack_xcd != value) drop_graph(); e->opt_stack_xcd = value; return DR_OK; }
-    if (n == "fused_rearm") { e->opt_rearm = value; return DR_OK; }
-    if (n == "blocked_accumulation") {
-        if (value != 1 && value != 2) return fail(e, DR_EINVAL, "blocked_accumulation is 1 or 2");
-        if (e->opt_blocked != value) drop_graph();
-        e->opt_blocked = value;
-        return DR_OK;
-    }
-    if (n == "fused_tail") { if (e->opt_tail != value) drop_graph(); e->opt_tail = value; return DR_OK; }
-    if (n == "fused_stack_warm") { if (e->opt_stack_warm != value) drop_graph(); e->opt_stack_warm = value; return DR_OK; }
-    if (n == "stack_fault_test") { if (e->opt_stack_fault != value) drop_graph(); e->opt_stack_fault = value; return DR_OK; }
-    if (n == "stack_ticks") { if (e->stack_dbg_on != value) drop_graph(); e->stack_dbg_on = value; return DR_OK; }
-    if (n.compare(0, 5, "tune.") == 0) {      // A/B knobs of planners and launchers: PROCESS-wide (kernels.h: Tuning)
-        Tuning& t = tuning();
-        const std::string f = n.substr(5);
-        int* field = f == "pack_threads" ? &t.pack_threads : f == "tile" ? &t.tile : f == "pw" ? &t.pw : f == "pw_nw" ? &t.pw_nw
-                   : f == "pwk" ? &t.pwk : f == "ksplit_max" ? &t.ksplit_max : f == "one_ks" ? &t.one_ks : f == "stack3" ? &t.stack3
-                   : f == "stack_fl" ? &t.stack_fl : f == "xcd_n" ? &t.xcd_n : f == "xcd_model" ? &t.xcd_model
-                   : f == "s3_eager" ? &t.s3_eager : f == "debug_chunks" ? &t.debug_chunks : nullptr;
-        if (f == "ksplit_blocks") { drop_graph(); t.ksplit_blocks = value; return DR_OK; }
-        if (!field) return fail(e, DR_ENAME, "unknown option '%s'", name);
-        if (*field != value) drop_graph();
-        *field = value;
-        return DR_OK;
-    }
-    return fail(e, DR_ENAME, "unknown option '%s'", name);
-}
-
-int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t* ticks, int n_ticks) {
-    if (!e) return DR_EINVAL;
-    if (!e->stack_bar) return fail(e, DR_ESTATE, "dr_commit has not been called");
-    DeviceGuard guard(e->cfg.device);
-    HIPCHK(e, hipDeviceSynchronize());
-    const unsigned flag = *e->stack_err_host;
-    if (timed_out) *timed_out = (int32_t)flag;
-    if (launches) *launches = e->stack_launches;
-    if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
-        int rc = clear_stack_timeout(e);
-        if (rc) return rc;
-    }
-    if (ticks && n_ticks > 0) {
-        long long h[128];
-        HIPCHK(e, hipMemcpy(h, e->stack_dbg, sizeof h, hipMemcpyDeviceToHost));
-        for (int i = 0; i < n_ticks && i < 128; ++i) ticks[i] = h[i];
-    }
-    return DR_OK;
-}
+int dr_set_option(dr_engine* e, const char* name, int value) { return drh::set_option(e, name, value, false); }
 
 int dr_set_spec_norm(dr_engine* e, int mode) {
     if (!e) return DR_EINVAL;

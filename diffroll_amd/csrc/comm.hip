@@ -18,6 +18,7 @@ constexpr int kUniqueIdBytes = 128;                 // NCCL_UNIQUE_ID_BYTES (rcc
 struct UniqueId { char internal[kUniqueIdBytes]; };  // ncclUniqueId: passed BY VALUE to ncclCommInitRank
 typedef void* Comm;                                  // ncclComm_t
 constexpr int kFloat32 = 7;                          // ncclFloat32
+constexpr int kInt32 = 2;                            // ncclInt32
 
 struct Rccl {
     void* lib = nullptr;
@@ -66,18 +67,15 @@ std::string nccl_err(const char* what, int rc) {
 struct dr_comm {
     Comm comm = nullptr;
     int n_ranks = 0, rank = 0, device = 0;
+    // validity of a gather is decided collectively: [0] = this rank's status word, [1 .. n_ranks] = everybody's (device),
+    // and a pinned host mirror the verdict is read from
+    int32_t* d_status = nullptr;
+    int32_t* h_status = nullptr;
 };
 
 extern "C" {
 
 const char* dr_comm_last_error(void) { return g_comm_error.c_str(); }
-
-int dr_rccl_version(int* version) {
-    if (!version) return cfail(DR_EINVAL, "null argument");
-    if (!rccl().lib) return cfail(DR_ESTATE, rccl().why);
-    int rc = rccl().GetVersion(version);
-    return rc ? cfail(DR_EHIP, nccl_err("ncclGetVersion", rc)) : DR_OK;
-}
 
 int dr_comm_unique_id(char* id_out) {
     if (!id_out) return cfail(DR_EINVAL, "null argument");
@@ -108,6 +106,22 @@ int dr_comm_create(dr_comm** out, const char* id, int n_ranks, int rank, int dev
     if (rc) return cfail(DR_EHIP, nccl_err("ncclCommInitRank", rc));
     dr_comm* h = new dr_comm();
     h->comm = c; h->n_ranks = n_ranks; h->rank = rank; h->device = device;
+    {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        void *d = nullptr, *hp = nullptr;
+        const bool ok = hipMalloc(&d, (size_t)(n_ranks + 1) * sizeof(int32_t)) == hipSuccess &&
+                        hipHostMalloc(&hp, (size_t)(n_ranks + 1) * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        if (!ok) {
+            if (d) (void)hipFree(d);
+            (void)rccl().CommDestroy(c);
+            delete h;
+            return cfail(DR_ENOMEM, "allocating the gather status words failed");
+        }
+        h->d_status = (int32_t*)d; h->h_status = (int32_t*)hp;
+    }
     *out = h;
     return DR_OK;
 }
@@ -115,13 +129,23 @@ int dr_comm_create(dr_comm** out, const char* id, int n_ranks, int rank, int dev
 void dr_comm_destroy(dr_comm* c) {
     if (!c) return;
     if (c->comm && rccl().lib) (void)rccl().CommDestroy(c->comm);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     delete c;
 }
 
-int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank) {
-    if (!c) return cfail(DR_EINVAL, "null argument");
-    if (n_ranks) *n_ranks = c->n_ranks;
-    if (rank) *rank = c->rank;
+int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank, int* rccl_version) {
+    if (c) {
+        if (n_ranks) *n_ranks = c->n_ranks;
+        if (rank) *rank = c->rank;
+    } else if (n_ranks || rank) {
+        return cfail(DR_EINVAL, "null communicator");
+    }
+    if (rccl_version) {
+        if (!rccl().lib) return cfail(DR_ESTATE, rccl().why);
+        int rc = rccl().GetVersion(rccl_version);
+        if (rc) return cfail(DR_EHIP, nccl_err("ncclGetVersion", rc));
+    }
     return DR_OK;
 }
 
@@ -132,16 +156,35 @@ int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, 
     // The one piece of engine state that matters here: a roll produced by a fused launch that timed out is invalid
     // (include/diffroll_amd.h: dr_finish).  A time-out is a PER-RANK event and the gather is collective: a rank that
     // returned before the collective would leave its peers blocked in ncclAllGather for ever.  So this rank still takes
-    // part (its shard is garbage, the peers' shards are not), and reports DR_ETIMEOUT afterwards: the caller recomputes
-    // its shard and gathers again - all ranks, since they all received the invalid shard.  `e` may be NULL.
+    // part - and tells everybody: behind the rolls every rank gathers one status word (0 valid, 1 invalid) on the same
+    // communicator and stream, and EVERY rank answers DR_ETIMEOUT when any word is set.  (Until round 5 only the rank
+    // that timed out knew; its peers got the garbage shard in d_full together with DR_OK.)  `e` may be NULL.
     const bool invalid = e && dr_pending_timeout(e, stream) != DR_OK;
+    hipStream_t st = (hipStream_t)stream;
     int prev = -1;
     (void)hipGetDevice(&prev);
     if (prev != comm->device && hipSetDevice(comm->device) != hipSuccess) return cfail(DR_EHIP, "hipSetDevice failed");
-    int rc = rccl().AllGather(d_shard, d_full, (size_t)B_local * T * 88, kFloat32, comm->comm, (hipStream_t)stream);
-    if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev);
-    if (rc) return cfail(DR_EHIP, nccl_err("ncclAllGather", rc));
-    return invalid ? cfail(DR_ETIMEOUT, dr_last_error(e)) : DR_OK;
+    auto back = [&]() { if (prev >= 0 && prev != comm->device) (void)hipSetDevice(prev); };
+    int rc = rccl().AllGather(d_shard, d_full, (size_t)B_local * T * 88, kFloat32, comm->comm, st);
+    if (rc) { back(); return cfail(DR_EHIP, nccl_err("ncclAllGather", rc)); }
+    const int n = comm->n_ranks;
+    comm->h_status[0] = invalid ? 1 : 0;
+    hipError_t he = hipMemcpyAsync(comm->d_status, comm->h_status, sizeof(int32_t), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        rc = rccl().AllGather(comm->d_status, comm->d_status + 1, 1, kInt32, comm->comm, st);
+        if (rc) { back(); return cfail(DR_EHIP, nccl_err("ncclAllGather (status words)", rc)); }
+        he = hipMemcpyAsync(comm->h_status + 1, comm->d_status + 1, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    back();
+    if (he != hipSuccess) return cfail(DR_EHIP, std::string("dr_gather: ") + hipGetErrorString(he));
+    int bad = -1, n_bad = 0;
+    for (int r = 0; r < n; ++r)
+        if (comm->h_status[1 + r]) { if (bad < 0) bad = r; ++n_bad; }
+    if (n_bad == 0) return DR_OK;
+    return cfail(DR_ETIMEOUT, "dr_gather: the shard of rank " + std::to_string(bad) + (n_bad > 1 ? " (and " + std::to_string(n_bad - 1) + " more)" : "") +
+                              " came out of a fused launch that timed out: d_full is invalid on every rank - that rank recomputes "
+                              "(dr_finish heals it), then all ranks gather again" + (invalid ? std::string("; this rank: ") + dr_last_error(e) : std::string()));
 }
 
 }  // extern "C"

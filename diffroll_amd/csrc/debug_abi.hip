@@ -1,11 +1,48 @@
-// Host side, part 4: measurement and checker entry points of the C-ABI (dr_profile_*, dr_bench_*, dr_debug_*): what
-// bench.py's roofline pass, tools/ and the checker builds call - nothing on the sampling path.
+// Host side, part 4: the entry points of include/diffroll_amd_debug.h - measurement, checker and test hooks (dr_profile_*,
+// dr_bench_*, dr_debug_*, dr_stack_status, dr_cold_times): what bench.py's roofline pass, tools/ and the checker builds call -
+// nothing on the sampling path.
 #include "engine_state.h"
 #include "tenants.h"
 
 using namespace drh;
 
 extern "C" {
+
+int dr_debug_set_option(dr_engine* e, const char* name, int value) { return drh::set_option(e, name, value, true); }
+
+int dr_debug_kfd_root(const char* kfd_root) {
+    drh::set_kfd_root(kfd_root);
+    return DR_OK;
+}
+
+int dr_cold_times(dr_engine* e, double* out5) {
+    if (!e || !out5) return DR_EINVAL;
+    out5[0] = e->t_pack_s; out5[1] = e->t_upload_s; out5[2] = e->t_tables_s; out5[3] = e->t_capture_s;
+    size_t nodes = 0;
+    if (e->graph && hipGraphGetNodes(e->graph, nullptr, &nodes) != hipSuccess) nodes = 0;
+    out5[4] = (double)nodes;
+    return DR_OK;
+}
+
+int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t* ticks, int n_ticks) {
+    if (!e) return DR_EINVAL;
+    if (!e->stack_bar) return fail(e, DR_ESTATE, "dr_commit has not been called");
+    DeviceGuard guard(e->cfg.device);
+    HIPCHK(e, hipDeviceSynchronize());
+    const unsigned flag = *e->stack_err_host;
+    if (timed_out) *timed_out = (int32_t)flag;
+    if (launches) *launches = e->stack_launches;
+    if (flag) {      // a barrier wait hit its spin bound: counters may be left armed - reset everything
+        int rc = clear_stack_timeout(e);
+        if (rc) return rc;
+    }
+    if (ticks && n_ticks > 0) {
+        long long h[128];
+        HIPCHK(e, hipMemcpy(h, e->stack_dbg, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_ticks && i < 128; ++i) ticks[i] = h[i];
+    }
+    return DR_OK;
+}
 
 int dr_profile_enable(dr_engine* e, int on) {
     if (!e) return DR_EINVAL;

@@ -22,7 +22,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/diffroll_amd.h"
+#include "../../include/diffroll_amd_debug.h"      // (includes the boundary, diffroll_amd.h)
 #include "kernels.h"
 
 namespace drh {
@@ -138,7 +138,12 @@ struct dr_engine {
     float* xalt = nullptr;              // the tail kernel writes x_{t-1} here (it must not update x_t in place: other
                                         // blocks still read it); the chain ping-pongs between this and its roll buffer
     int64_t stack_fallbacks = 0;        // time-outs detected by dr_finish: each one switched this engine to per-phase launches
-    int64_t stack_yields = 0;           // times this engine gave up fusing because the device turned out to be shared (no time-out)
+    int64_t stack_yields = 0;           // times this engine gave up fusing because another process was computing on the device (no time-out)
+    int64_t stack_rearms = 0;           // times fused launches were switched back on (after a time-out: fused_rearm; after a yield: clean looks)
+    int yielded_from = 0;               // the fused_stack value a yield switched off (0: none pending)
+    int yield_clean = 0;                // looks in a row, in front of later chains, that found the GPU exclusive again
+    int last_mode = 0;                  // DR_MODE_* of the most recently planned evaluation (dr_launch_state)
+    unsigned tuning_epoch = 0;          // tuning_epoch() when the cached chain was captured
     long kfd_gpu_id = -1;               // the driver's id of this GPU in /sys/class/kfd (tenants.h); -1: unknown, no scans
     double last_tenant_scan_s = -1.0;
     hipStream_t graph_stream = nullptr; // where the captured chain was last launched
@@ -226,6 +231,11 @@ struct Range {
     Range(const Range&) = delete;
     Range& operator=(const Range&) = delete;
 };
+
+// ---- abi.hip
+int clear_stack_timeout(dr_engine* e);
+int set_option(dr_engine* e, const char* name, int value, bool lab);      // lab: the names of dr_debug_set_option too
+void set_kfd_root(const char* root);                                      // dr_debug_kfd_root
 
 // ---- pack.hip
 int dev_alloc(dr_engine* e, float** p, size_t floats, bool zero = true);

@@ -22,6 +22,7 @@
 namespace dr {
 
 Tuning& tuning() { static Tuning t; return t; }
+std::atomic<unsigned>& tuning_epoch() { static std::atomic<unsigned> n{0}; return n; }
 
 DR_BOUNDS_TU(gemm)
 hipError_t read_bounds(unsigned long long* out4) {
@@ -347,7 +348,8 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi) {
 
 KSplitPlan plan_ksplit(long tiles, int nchunks, int kchunks, int taps, int NI, int prec, size_t ws_floats, size_t ws_cnt_n) {
     const int ks_max = tuning().ksplit_max;
-    const long max_blocks = tuning().ksplit_blocks ? tuning().ksplit_blocks : (prec ? 256 : 2048);
+    const long forced_blocks = tuning().ksplit_blocks.load();
+    const long max_blocks = forced_blocks ? forced_blocks : (prec ? 256 : 2048);
     const int BN = gemm_block_frames(NI);
     const double t_full = (double)kchunks * taps * 16.0 * (BN / 32) * 69.0 / 2400.0;
     auto cost = [&](int ks) {

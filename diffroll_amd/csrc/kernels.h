@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace dr {
 
 // ---------------------------------------------------------------------------------------------
@@ -28,23 +30,28 @@ namespace dr {
 // A/B knobs of the planners and launchers (process-wide; defaults = what ships).  They are set through
 // dr_set_option(e, "tune.<field>", value) by tools/ and tests - the library reads no environment variable.
 // ---------------------------------------------------------------------------------------------
+// Fields are atomics (relaxed loads / stores are all that is needed: independent integers): dr_debug_set_option may run on
+// one host thread while another engine's planner reads them.  Every change bumps tuning_epoch(); an engine compares it in
+// dr_sample and drops a chain it captured under older values.
 struct Tuning {
-    int pack_threads = 16;   // host threads packing the layers at dr_commit (1 = serial)
-    int tile = 0;            // force a conv / LDS-staged 1x1 tile: 3201 / 3202 / 3203 / 3205 (32x32 MFMA, NI) or 1603 / 1605 (16x16, NJ); 0 = cost model
-    int pw = 1;              // 1x1 residual/skip GEMM: 1 = operands direct from L2 (pw_kernel), 0 = the LDS-staged kernels
-    int pw_nw = 0;           // force 32 * pw_nw frames per pw_kernel block (2..5); 0 = cost model
-    int pwk = 1;             // under-filled 1x1 launches: K split over the block's waves (pwk_kernel)
-    int ksplit_max = 16;     // largest split-K factor of gemm_kernel launches (1 = never split)
-    long ksplit_blocks = 0;  // cap on tiles x ksplit (0 = 2048 fp32 / 256 split-bf16)
-    int one_ks = 0;          // force the 1x1 GEMMs' channels-per-hand-over (KS = 1 / 2 / 4); 0 = by divisibility
-    int stack3 = 1;          // the split-bf16 flavour of the fused residual stack
-    int stack_fl = 0;        // force the fused stack's block flavour (1 = 64-frame, 2 = 128-frame blocks); 0 = cost model
-    int xcd_n = -1;          // force the block -> XCD mapping of per-phase GEMM launches (0 / 1); -1 = traffic model
-    int xcd_model = 1;       // 0 = the rounds 1-2 rule (activation bytes > weight bytes)
-    int s3_eager = 0;        // build the split-bf16 packings at every dr_commit (rounds 1-3 behaviour)
-    int debug_chunks = 0;    // dr_debug_ticks prints the chunk-start tick marks
+    std::atomic<int> pack_threads{16};   // host threads packing the layers at dr_commit (1 = serial)
+    std::atomic<int> tile{0};            // force a conv / LDS-staged 1x1 tile: 3201 / 3202 / 3203 / 3205 (32x32 MFMA, NI) or 1603 / 1605 (16x16, NJ); 0 = cost model
+    std::atomic<int> pw{1};              // 1x1 residual/skip GEMM: 1 = operands direct from L2 (pw_kernel), 0 = the LDS-staged kernels
+    std::atomic<int> pw_nw{0};           // force 32 * pw_nw frames per pw_kernel block (2..5); 0 = cost model
+    std::atomic<int> pwk{1};             // under-filled 1x1 launches: K split over the block's waves (pwk_kernel)
+    std::atomic<int> ksplit_max{16};     // largest split-K factor of gemm_kernel launches (1 = never split)
+    std::atomic<long> ksplit_blocks{0};  // cap on tiles x ksplit (0 = 2048 fp32 / 256 split-bf16)
+    std::atomic<int> one_ks{0};          // force the 1x1 GEMMs' channels-per-hand-over (KS = 1 / 2 / 4); 0 = by divisibility
+    std::atomic<int> stack3{1};          // the split-bf16 flavour of the fused residual stack
+    std::atomic<int> stack_fl{0};        // force the fused stack's block flavour (1 / 2 / 5 = 64 / 128 / 160-frame blocks); -5 = never the 160-frame one; 0 = cost model
+    std::atomic<int> tail_t4{0};         // force the item width of the tail kernel's first-layer conv (1 = 64, 3 = 96 frames); 0 = by rounds x width
+    std::atomic<int> xcd_n{-1};          // force the block -> XCD mapping of per-phase GEMM launches (0 / 1); -1 = traffic model
+    std::atomic<int> xcd_model{1};       // 0 = the rounds 1-2 rule (activation bytes > weight bytes)
+    std::atomic<int> s3_eager{0};        // build the split-bf16 packings at every dr_commit (rounds 1-3 behaviour)
+    std::atomic<int> debug_chunks{0};    // dr_debug_ticks prints the chunk-start tick marks
 };
 Tuning& tuning();            // gemm.hip
+std::atomic<unsigned>& tuning_epoch();
 
 enum Epilogue : int {
     EPI_PLAIN = 0,     // y = alpha*acc + bias
@@ -225,7 +232,7 @@ hipError_t launch_update(const UpdateArgs& a, hipStream_t s);
 // stack_kernel launch it follows: NB samples (first `dual` conditional, next `dual` unconditional when dual > 0) x
 // ceil(T / BN) frame tiles x Cp / 64 blocks, all resident at once.
 struct TailArgs {
-    int NB, T, Cp, BN;                        // BN = frames per block of the preceding stack launch (64 / 128): grouping only
+    int NB, T, Cp, BN;                        // BN = frames per block of the preceding stack launch (64 / 128 / 160): grouping only
     int dual;                                 // B > 0: classifier-free pairs (sample b, sample b + B); 0: every sample on its own
     int u_B;                                  // rolls to update (B)
     int xcd_n, fault;
@@ -243,6 +250,7 @@ struct TailArgs {
     long c_bs;
     int taps, dil;
     int fold;                                 // blocked accumulation in that conv (gemm_body.h), as the stack launch that follows
+    int t4_ni;                                // in: 0 = the launcher chooses T4's item width, 1 / 3 = force 64 / 96 frames; the launcher sets 1 or 3
     float* g;                                 // its output, P4 [NB][Cp/4][T][4]
     int lds_bytes;                            // set by the launcher
     long long* dbg;                           // optional: block 0 writes s_memtime at the start and after T1, its barrier, T2, its

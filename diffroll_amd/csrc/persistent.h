@@ -3,6 +3,15 @@
 #pragma once
 #include "device_common.h"
 
+// Test hook of the time-out path (option "stack_fault_test" of dr_debug_set_option): only libraries built with -DDR_FAULT_HOOK
+// (variant "hook", diffroll_amd/build.py) let a launch ask its group barriers for one arrival more than a group has - the
+// production library compiles the term away and knows no such option.
+#ifdef DR_FAULT_HOOK
+#define DR_FAULT_EXTRA(s) ((unsigned)(s).fault)
+#else
+#define DR_FAULT_EXTRA(s) 0u
+#endif
+
 namespace dr {
 
 // ---------------------------------------------------------------------------------------------

@@ -206,8 +206,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
     if (e->opt_stack && (prec == 0 || (stack3 && Cp % 128 == 0)) && L <= DR_STACK_MAX_LAYERS && e->n_cus > 0) {
         int maxdil = 1;
         for (int l = 0; l < L; ++l) maxdil = std::max(maxdil, e->layers[l].dil);
-        // Flavours 1 / 2 (128 packed rows x 64 / 128 frames per block) are chosen automatically; tune.stack_fl = n pins one
-        // (tests / measurements).
+        // Flavours 1 / 2 / 5 (128 packed rows x 64 / 128 / 160 frames per block) are chosen automatically; tune.stack_fl = n
+        // pins one (tests / measurements); tune.stack_fl = -5 excludes the 160-frame flavour (its A/B).  Flavour 5 exists in
+        // exact fp32 with blocked accumulation only (its per-phase twin is gemm_kernel<5>, which has no other form).
         const int fl_force = tuning().stack_fl;
         // A launch must be ONE resident round (groups spin on each other), so an evaluation with more samples than
         // fit is launched in balanced CHUNKS of samples, one fused launch after the other (samples are independent).
@@ -229,8 +230,9 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             return best;
         };
         double best = 1e30;
-        for (int fl : {1, 2}) {
-            if (fl_force && fl != fl_force) continue;
+        for (int fl : {1, 2, 5}) {
+            if (fl_force > 0 && fl != fl_force) continue;
+            if (fl == 5 && (fl_force == -5 || prec != 0 || e->opt_blocked < 2)) continue;
             const int bn = stack_tile_frames(fl);
             const long gsize = stack_group_blocks(fl, Cp, T);                           // blocks per sample
             const long cap = std::min<long>(e->n_cus, 1024) / gsize;                    // samples per launch
@@ -239,7 +241,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             if ((NB + chunks - 1) / chunks > dr_engine::STACK_GROUPS) continue;
             // (what fusing saves is per-launch overhead, which the per-phase launches amortise over their rounds:
             // measured +2.5 % at one round, +1.1 % at two (B = 32 guided clips per GPU), nothing at four)
-            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : 1.0);
+            const double cost = (1.0 - 0.025 / chunks) * chunks * bn * (fl == 1 ? 1.0 / 0.93 : fl == 5 ? 1.04 : 1.0);
             // (a single launch that leaves more than a fifth of the CUs idle is better served by the per-phase kernels'
             // split-K, which this cost model does not see: they cut the same work into many short blocks that balance
             // over all CUs - 8 evaluations x 125 frames (half the chip): 1365 vs 2422 us per step, 10 / 12 evaluations
@@ -256,6 +258,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
         fused_step = stack_ni && stack_chunks == 1 && e->opt_tail && !tsel && prec == 0;      // (the tail kernel is fp32 only)
     }
     const bool use_tail = fused_step && tail != nullptr;
+    e->last_mode = use_tail ? DR_MODE_FUSED_STACK_TAIL : (stack_from >= 0 ? DR_MODE_FUSED_STACK : DR_MODE_PER_PHASE);      // dr_launch_state
     // input projection + relu (model/diffwave.py:667-668) - unless the previous step's tail kernel already wrote h / hd
     if (!(use_tail && tail->skip_inproj)) {
         GemmArgs a{};
@@ -357,7 +360,12 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
             // both halves convolve the same h + d_0, so the contraction is done once per pair and the epilogue
             // writes both gated outputs (conditioner of b / constant unconditional bias).  Bit-identical.
             const bool dual = (l == 0 && bmod > 0 && NB == 2 * bmod && n_cond == bmod);
-            if (dual) { a.NB = bmod; a.dual = bmod; a.nofold64 = (stack_ni == 2 && e->opt_blocked < 2); }
+            if (dual) {
+                a.NB = bmod; a.dual = bmod; a.nofold64 = (stack_ni == 2 && e->opt_blocked < 2);
+                // (the single-chain 64-frame instance exists unsplit only, and it must be THE instance that runs - the tail
+                // kernel's copy of this conv is what it has to agree with bit for bit: no split-K for this launch)
+                if (a.nofold64) { a.ws = nullptr; a.ws_cnt = nullptr; }
+            }
             const Tile tile = dual ? pick_tile(Cp / 64, bmod, T, e->K, w.dil, prec, EPI_GATE, false, e->opt_blocked >= 2)
                                    : pick_tile(Cp / 64, NB, T, e->K, w.dil, prec, EPI_GATE, true, e->opt_blocked >= 2);
             if (e->stack_dbg_on && l + 1 == L) a.dbg = e->stack_dbg + 64;
@@ -424,6 +432,7 @@ int run_network(dr_engine* e, const float* xin, int bmod, int NB, int n_cond, in
                 ta.c_bs = (long)2 * Cp * T;
                 ta.taps = e->K; ta.dil = w0.dil;
                 ta.fold = (stack_ni != 2 || e->opt_blocked >= 2);
+                ta.t4_ni = tuning().tail_t4;
                 ta.g = e->g;
             }
         }

@@ -7,7 +7,10 @@ namespace dr {
 
 DR_BOUNDS_TU(stack)
 
-// FL = block flavour (on the 32x32x2 MFMA): 1 / 2 = 128 packed rows x 64 / 128 frames (gemm_body<FL>).
+// FL = block flavour (on the 32x32x2 MFMA): 1 / 2 = 128 packed rows x 64 / 128 frames (gemm_body<FL>); 5 = 128 packed rows x
+// 160 frames (gemm_body<5>: five 32-frame MFMA tiles per consumer wave, blocked accumulation only) for the 640-frame
+// geometries - 8 evaluations x 4 frame tiles x 8 M tiles = 256 blocks = one resident round, one 32-block group per XCD; its
+// 1x1 phases run on all eight waves, waves 0-3 on frames [0, 96) and waves 4-7 on frames [96, 160) of the block's tile.
 // (Two more flavours were built, measured and removed: 160-frame blocks on the 16x16x4 MFMA for 640-frame clips, rounds
 // 2-3 - never faster than the per-phase launches there, 92 spilled registers; and HALF tiles of 64 packed rows x 128
 // frames with K split over the block's wave pairs, round 4, for BASELINE config 3's 16 evaluations x 125 frames - every
@@ -30,8 +33,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
     typedef const __attribute__((address_space(4))) StackArgs* KernArgs;
     const KernArgs sp = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const __attribute__((address_space(4))) StackArgs& s = *sp;
-    static_assert(FL == 1 || FL == 2, "block flavours");
-    constexpr int BN = 64 * FL;
+    static_assert(FL == 1 || FL == 2 || (FL == 5 && FOLDP == 1 && PREC == 0), "block flavours");
+    constexpr int BN = FL == 5 ? 160 : 64 * FL;
     constexpr int RP = 32;                                 // planes (4 rows each) of the block's resident tile
     constexpr int RWL = (BN + 63) / 64;                    // 64-frame segments of a tile row
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -215,6 +218,13 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // the phase takes the same cycles at a lower clock (485.4 vs 483.3 ms).
             if constexpr (FL == 2) {
                 if (!idle) pw_body<2, 1, 1, 128>(a, mt, nt, wave & 3, Rs, (wave >> 2) * 64);
+            } else if constexpr (FL == 5) {
+                // 160-frame flavour: waves 0-3 take frames [0, 96) (three MFMA tiles), waves 4-7 frames [96, 160) (two) of
+                // the same rows - five tiles per SIMD as in the conv phase, shared by two MFMA streams
+                if (!idle) {
+                    if (wave < 4) pw_body<3, 1, 1, 160>(a, mt, nt, wave, Rs, 0);
+                    else pw_body<2, 1, 1, 160>(a, mt, nt, wave - 4, Rs, 96);
+                }
             } else {
                 if (wave < 4 && !idle) pw_body<BN / 32, 1, 1>(a, mt, nt, wave, Rs);
             }
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
             // (no acquire here: a conv phase reads hd with L1-bypassing sc1 LDS-DMA loads, and the 1x1 phase's L1
             // invalidate was issued by a producer wave during the conv phase, above)
             // (s.fault: test hook - one arrival more than the group has is awaited, so every wait runs into its bound)
-            group_barrier<false>(ctr, ++episode * (gsize + (unsigned)s.fault), s.err, s.derr);
+            group_barrier<false>(ctr, ++episode * (gsize + DR_FAULT_EXTRA(s)), s.err, s.derr);
             if (episode == 1) {      // every block of the group has published its (generation, XCC id): one L2 for all?
                 if (threadIdx.x == 0) {
                     unsigned same = 1;
@@ -276,8 +286,8 @@ __global__ __launch_bounds__(512) void stack_kernel(const StackArgs s_by_value) 
 }
 
 hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st, int prec) {
-    if (FL != 1 && FL != 2) return hipErrorInvalidValue;
-    if (prec && (s.Cp & 127)) return hipErrorInvalidValue;
+    if (FL != 1 && FL != 2 && FL != 5) return hipErrorInvalidValue;
+    if (prec && ((s.Cp & 127) || FL == 5)) return hipErrorInvalidValue;
     if (s.L < 1 || s.L > DR_STACK_MAX_LAYERS || s.p0 < 0 || s.p1 > 2 * s.L || s.p0 >= s.p1 || (s.Cp & 63)) return hipErrorInvalidValue;
     const int BN = stack_tile_frames(FL), MT = s.Cp >> 6, gsize = stack_group_blocks(FL, s.Cp, s.T);
     const size_t lds = prec ? stack3_lds_bytes(FL, s.taps, max_dil) : stack_lds_bytes(FL, s.taps, max_dil);
@@ -309,12 +319,13 @@ hipError_t launch_stack(const StackArgs& s, int FL, int max_dil, hipStream_t st,
         return hipGetLastError();
     }
     if (FL == 1) hipLaunchKernelGGL((stack_kernel<1>), grid, dim3(512), lds, st, b);
+    else if (FL == 5) hipLaunchKernelGGL((stack_kernel<5>), grid, dim3(512), lds, st, b);
     else if (FL == 2 && s.fold128) hipLaunchKernelGGL((stack_kernel<2, 1>), grid, dim3(512), lds, st, b);
     else if (FL == 2) hipLaunchKernelGGL((stack_kernel<2, 0>), grid, dim3(512), lds, st, b);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-int stack_tile_frames(int FL) { return 64 * FL; }
+int stack_tile_frames(int FL) { return FL == 5 ? 160 : 64 * FL; }
 // split-bf16 flavour: max over its two phase bodies (conv: S3 X tiles; 1x1: 128-channel S3 X tiles + the 64-frame h / skip tile)
 size_t stack3_lds_bytes(int FL, int taps, int max_dil) {
     return std::max(gemm_lds_bytes(FL, 1, taps, max_dil, 1, EPI_GATE), gemm_lds_bytes(1, 4, 1, 1, 1, EPI_RES_SKIP)) + 16;
@@ -334,6 +345,7 @@ hipError_t init_stack_kernels() {
     hipError_t e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<1, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(&stack_kernel<2, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
             for (int it = member; it < n1; it += (int)gsize) pw_body<2, 1, 0, 64, EPI_RELU>(a, it % a.MT, grp * tps64 + it / a.MT, wave);
     }
     mark();
-    group_barrier<true>(ctr, gsize + (unsigned)s.fault, s.err, s.derr);
+    group_barrier<true>(ctr, gsize + DR_FAULT_EXTRA(s), s.err, s.derr);
     mark();
     // ---- T2: output projection (88 x C) into the roll layout
     const int tps32 = (s.T + 31) >> 5;
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
             for (int it = member; it < tps32; it += (int)gsize) pw_body<1, 1, 0, 32, EPI_PLAIN>(a, 0, grp * tps32 + it, wave);
     }
     mark();
-    if (paired) group_barrier<true>(pctr, 2u * gsize + (unsigned)s.fault, s.err, s.derr);
-    else group_barrier<true>(ctr, 2u * (gsize + (unsigned)s.fault), s.err, s.derr);
+    if (paired) group_barrier<true>(pctr, 2u * gsize + DR_FAULT_EXTRA(s), s.err, s.derr);
+    else group_barrier<true>(ctr, 2u * (gsize + DR_FAULT_EXTRA(s)), s.err, s.derr);
     mark();
     // ---- T3: combine + update (+ the next step's input projection) per (row tile, 32-frame chunk) of the pair's clip
     if (pair_i < s.u_B) {       // (groups without a roll of their own - none today - would skip)
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
     mark();
     // ---- T4: the next step's shared first-layer conv (pairs only)
     if (paired && s.conv_w) {
-        group_barrier<false>(pctr, 2u * (2u * gsize + (unsigned)s.fault), s.err, s.derr);
+        group_barrier<false>(pctr, 2u * (2u * gsize + DR_FAULT_EXTRA(s)), s.err, s.derr);
         mark();
         GemmArgs a{};
         a.d2 = s.zero; a.wt_store = 0;                    // g is consumed by the NEXT launch: plain stores
@@ -179,14 +179,18 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
         a.cond = s.cond; a.cond2 = s.cond2; a.c_bs = s.c_bs; a.n_cond = s.dual;
         a.dual = s.dual;
         a.Y = s.g;
-        const int tps64 = (s.T + 63) >> 6;
-        const int n4 = MT * tps64;
+        // item width (launch_tail): 64 frames, or 96 where that needs fewer x narrower rounds over the pair's blocks (640-frame
+        // clips in 32-block groups: 56 items of 96 frames = one round instead of 80 items of 64 frames = two)
+        const int bn4 = s.t4_ni == 3 ? 96 : 64;
+        const int tps4 = (s.T + bn4 - 1) / bn4;
+        const int n4 = MT * tps4;
         for (int it = pair_half * (int)gsize + member; it < n4; it += 2 * (int)gsize) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                              // (the LDS tiles of the previous item / of T3 are free)
             // (same accumulation order as the stack launch that consumes g: blocked unless that is the unblocked 128-frame flavour)
-            if (s.fold) gemm_body<1, 1, EPI_GATE, 0, 1, 1>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
-            else gemm_body<1, 1, EPI_GATE, 0, 1, 0>(a, smem, it % MT, pair_i * tps64 + it / MT, 0);
+            if (s.t4_ni == 3) gemm_body<3, 1, EPI_GATE, 0, 1, 1>(a, smem, it % MT, pair_i * tps4 + it / MT, 0);
+            else if (s.fold) gemm_body<1, 1, EPI_GATE, 0, 1, 1>(a, smem, it % MT, pair_i * tps4 + it / MT, 0);
+            else gemm_body<1, 1, EPI_GATE, 0, 1, 0>(a, smem, it % MT, pair_i * tps4 + it / MT, 0);
         }
     }
     if (s.dbg && blockIdx.x == 0 && threadIdx.x == 0) s.dbg[7] = clock64();
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(512) void tail_kernel(const TailArgs s) {
 }
 
 hipError_t launch_tail(const TailArgs& s, hipStream_t st) {
-    if (s.BN != 64 && s.BN != 128) return hipErrorInvalidValue;
+    if (s.BN != 64 && s.BN != 128 && s.BN != 160) return hipErrorInvalidValue;
     if ((s.Cp & 63) || s.NB < 1 || s.T < 1) return hipErrorInvalidValue;
     if (s.dual > 0 && s.NB != 2 * s.dual) return hipErrorInvalidValue;
     if (!s.x_out || s.x_out == s.u.x) return hipErrorInvalidValue;
@@ -218,7 +222,13 @@ hipError_t launch_tail(const TailArgs& s, hipStream_t st) {
     size_t lds = 24 * 32 * 16;
     if (s.conv_w) {
         if (s.dual <= 0 || (s.taps & 1) == 0) return hipErrorInvalidValue;
-        lds = std::max(lds, gemm_lds_bytes(1, 1, s.taps, s.dil, 0, EPI_GATE));
+        // T4's item width: rounds over the pair's 2 * gsize blocks x frames per item, 64 unless 96 is strictly cheaper (the
+        // 96-frame body exists with blocked accumulation only)
+        const long pair_blocks = 2L * MT * tps;
+        const long n64 = (long)MT * ((s.T + 63) / 64), n96 = (long)MT * ((s.T + 95) / 96);
+        const long c64 = (n64 + pair_blocks - 1) / pair_blocks * 64, c96 = (n96 + pair_blocks - 1) / pair_blocks * 96;
+        b.t4_ni = (s.fold && s.t4_ni != 1 && (c96 < c64 || s.t4_ni == 3)) ? 3 : 1;
+        lds = std::max(lds, gemm_lds_bytes(b.t4_ni, 1, s.taps, s.dil, 0, EPI_GATE));
         if (lds > 160 * 1024) return hipErrorInvalidValue;
     }
     b.lds_bytes = (int)lds;

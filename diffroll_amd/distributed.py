@@ -91,18 +91,20 @@ class NativeComm:
     def rccl_version(self) -> int:
         import ctypes as C
         v = C.c_int(0)
-        if self.lib.dr_rccl_version(C.byref(v)) != 0:
+        if self.lib.dr_comm_info(self.h, None, None, C.byref(v)) != 0:
             raise RuntimeError(self.lib.dr_comm_last_error().decode())
         return int(v.value)
 
-    def all_gather(self, local: torch.Tensor) -> torch.Tensor:
-        """(b, 1, T, 88) or (b, T, 88) fp32 on the communicator's device -> (world * b, ...), rank-major."""
+    def all_gather(self, local: torch.Tensor, engine=None) -> torch.Tensor:
+        """(b, 1, T, 88) or (b, T, 88) fp32 on the communicator's device -> (world * b, ...), rank-major.  Synchronous.
+        engine (optional, the Engine that produced `local`): its pending fused-kernel time-out, if any, is reported to EVERY
+        rank of the gather (dr_gather's status word) - all of them raise, none keeps a result that holds the invalid shard."""
         local = local.contiguous()
         assert local.device == self.device and local.dtype == torch.float32 and local.shape[-1] == 88
         b, T = local.shape[0], local.shape[-2]
         out = torch.empty((self.world_size * b,) + tuple(local.shape[1:]), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self.lib.dr_gather(None, self.h, local.data_ptr(), out.data_ptr(), b, T,
+            rc = self.lib.dr_gather(engine.h if engine is not None else None, self.h, local.data_ptr(), out.data_ptr(), b, T,
                                     torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
             raise RuntimeError(f"dr_gather failed ({rc}): " + self.lib.dr_comm_last_error().decode())

@@ -210,12 +210,26 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.lib.dr_finish(self.h, self._stream()))
 
+    def launch_state(self) -> dict:
+        """dr_launch_state: how this engine launches the residual layers and what has happened to that decision -
+        {'mode': 'per_phase' | 'fused_stack' | 'fused_stack+tail' | 'none', 'fused_enabled', 'fallbacks', 'yields', 'rearms',
+        'stack_launches', 'tail_launches'}.  A measurement checks that fallbacks / yields did not move under it."""
+        info = _cabi.DrLaunchInfo()
+        self._check(self.lib.dr_launch_state(self.h, C.byref(info)))
+        out = {name: int(getattr(info, name)) for name, _ in _cabi.DrLaunchInfo._fields_}
+        out["mode"] = _cabi.MODES.get(out["mode"], str(out["mode"]))
+        return out
+
     @property
     def fallbacks(self) -> int:
         """How many fused-kernel time-outs this engine has detected and healed (0 in a healthy run)."""
-        n = C.c_int64(0)
-        self._check(self.lib.dr_stack_fallbacks(self.h, C.byref(n)))
-        return int(n.value)
+        return self.launch_state()["fallbacks"]
+
+    @property
+    def yields(self) -> int:
+        """How many times this engine gave up fusing because another process was computing on its GPU (0 on a GPU of
+        its own)."""
+        return self.launch_state()["yields"]
 
     def cold_times(self):
         """(pack_s, upload_s, tables_s of the last dr_commit; capture + instantiate seconds and kernel-node count of the
@@ -237,9 +251,7 @@ class Engine:
     @property
     def tail_launches(self) -> int:
         """Tail-kernel launches issued so far (option 'fused_tail')."""
-        n = C.c_int64(0)
-        self._check(self.lib.dr_tail_launches(self.h, C.byref(n)))
-        return int(n.value)
+        return self.launch_state()["tail_launches"]
 
     def sample(self, sampler: str, x: torch.Tensor, noise: Optional[torch.Tensor], w: float = 0.0,
                seed: int = 0, first_sample: int = 0, use_graph: bool = True, check: bool = True) -> torch.Tensor:
@@ -315,9 +327,11 @@ class Engine:
         return n.value, ms.value, fl.value, buf.value.decode()
 
     def set_option(self, name: str, value: int):
-        """Integer options of the engine - 'fused_stack', 'fused_tail', 'fused_rearm', 'blocked_accumulation', ... :
-        include/diffroll_amd.h, dr_set_option.  Unknown names and values out of range raise ValueError."""
-        self._check(self.lib.dr_set_option(self.h, name.encode(), int(value)))
+        """Integer options of the engine: 'fused_stack', 'fused_tail', 'fused_rearm', 'blocked_accumulation' (dr_set_option,
+        include/diffroll_amd.h); any other name - 'tune.*', 'fused_stack_xcd', 'stack_ticks', ... - is a lab knob
+        (dr_debug_set_option, include/diffroll_amd_debug.h).  Unknown names and values out of range raise ValueError."""
+        fn = self.lib.dr_set_option if name in _cabi.PUBLIC_OPTIONS else self.lib.dr_debug_set_option
+        self._check(fn(self.h, name.encode(), int(value)))
 
     def stack_status(self, n_ticks: int = 0):
         """(timed_out, ticks): synchronises; timed_out != 0 means a fused-kernel barrier hit its spin bound.

@@ -275,12 +275,13 @@ class ClassifierFreeDiffRoll(nn.Module):
         return self
 
     @classmethod
-    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides):
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, trust=False, **overrides):
         """Lightning-style: ``{'state_dict', 'hyper_parameters'}``; keyword overrides win
         (sampling.py:54-65).  OmegaConf containers inside a real reference checkpoint are read without
-        omegaconf / pytorch_lightning installed (diffroll_amd/checkpoint.py)."""
+        omegaconf / pytorch_lightning installed, and without executing anything the file names: an allow-listing
+        unpickler (diffroll_amd/checkpoint.py); ``trust=True`` = the full unpickle Lightning itself does."""
         from .checkpoint import constructor_kwargs, load_checkpoint
-        ckpt = load_checkpoint(checkpoint_path)
+        ckpt = load_checkpoint(checkpoint_path, trust=trust)
         m = cls(**constructor_kwargs(cls, ckpt["hyper_parameters"], overrides))
         m.load_state_dict(ckpt["state_dict"], strict=False)
         return m

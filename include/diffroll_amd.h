@@ -25,6 +25,10 @@
  * torch.cuda.current_stream().cuda_stream).  Every function returns 0 on success or a negative
  * DR_E* code and never throws; the message is available from dr_last_error().  An engine handle
  * is not re-entrant: one handle per (device, stream), one host thread at a time.
+ *
+ * This header is the WHOLE boundary (30 functions).  Measurement, checker and test entry points of the same library
+ * (dr_profile_*, dr_bench_*, dr_debug_*, dr_stack_status, dr_cold_times, the A/B options "tune.*") are declared in
+ * diffroll_amd_debug.h; nothing on the sampling path needs them.
  */
 #ifndef DIFFROLL_AMD_H
 #define DIFFROLL_AMD_H
@@ -36,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 9
+#define DR_ABI_VERSION 10
 
 enum {
     DR_OK = 0,
@@ -202,11 +206,13 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  * its workgroups are resident on the device at once; when something else holds CUs while it runs (a second engine,
  * stream or process computing on the same device) a group barrier can run into its spin bound - the launch then
  * carries on with wrong data, raises a flag, and every later fused launch of the engine returns immediately.
- * (Since ABI 9 an engine avoids most of these by YIELDING first: engines of one process take turns on a per-device slot -
- * the one that finds another engine's fused work still in flight switches to one launch per phase instead of waiting - and
- * dr_create / dr_sample look for another PROCESS computing on the GPU in the kernel driver's process list
- * (/sys/class/kfd/kfd/proc: csrc/tenants.h) and yield to it too, with one line on stderr.  The spin bound remains the
- * backstop for what those checks cannot see: a tenant that arrives in the middle of a chain.)
+ * (An engine avoids most of these BEFORE it launches.  Engines of one process take turns on a per-device slot: the one
+ * that finds another engine's fused work still in flight orders its own launches behind it on the device (a stream
+ * wait on an event: no host wait, nobody gives up fusing).  And dr_create / dr_sample look for another PROCESS computing
+ * on the GPU in the kernel driver's process list (/sys/class/kfd/kfd/proc: csrc/tenants.h): if there is one the engine
+ * YIELDS - one launch per phase from then on, same results, one line on stderr, counted in dr_launch_state - and goes
+ * back to fused launches once two looks in a row, in front of later chains, find the GPU its own again.  The spin bound
+ * remains the backstop for what those checks cannot see: a tenant that arrives in the middle of a chain.)
  * dr_finish synchronises `stream` and checks that flag:
  *   DR_OK        everything issued on this engine since the last check is valid;
  *   DR_ETIMEOUT  it is NOT: recompute it.  The condition has been cleared and the engine switched to one launch per
@@ -218,9 +224,9 @@ int dr_sample(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B
  * (dr_note_runs, dr_frame_counts, dr_q_sample / dr_extract_x0, dr_gather) first does what dr_pending_timeout does -
  * it synchronises the stream the fused launches ran on (and `stream`) if any have been issued since the last check - and
  * returns DR_ETIMEOUT instead of working on an invalid roll; dr_gather still takes part in the collective first (a time-out
- * is a per-rank event: a rank that stayed out would leave its peers blocked) and reports DR_ETIMEOUT afterwards - the shard
- * this rank contributed is invalid, every rank must gather again after it has been recomputed.  Only dr_finish (and
- * dr_stack_status) clear the condition.
+ * is a per-rank event: a rank that stayed out would leave its peers blocked) and reports DR_ETIMEOUT afterwards - ON EVERY
+ * RANK (a status word travels with the rolls): every rank must gather again after the invalid shard has been recomputed.
+ * Only dr_finish clears the condition.
  */
 int dr_finish(dr_engine* e, void* stream);
 /* The check alone: DR_ETIMEOUT when a fused launch issued on this engine has timed out and dr_finish has not been called
@@ -233,14 +239,30 @@ int dr_pending_timeout(dr_engine* e, void* stream);
  * a finished roll, never a silently invalid one. */
 int dr_sample_checked(dr_engine* e, int sampler, float* d_x, const float* d_noise, int B, int T,
                       float w, uint64_t seed, int first_sample, int use_graph, int32_t* recovered, void* stream);
-/* how many time-outs dr_finish has detected (and healed) on this engine so far */
-int dr_stack_fallbacks(dr_engine* e, int64_t* count);
-/* Start-up costs of this engine, seconds (a one-shot process - sampling.py: load checkpoint, one batch - pays them once):
- * out5 = {host-side weight packing of the last dr_commit, its uploads, its device-built tables (step embedding),
- * capture + instantiation of the last chain graph, kernel nodes of that graph}. */
-int dr_cold_times(dr_engine* e, double* out5);
-/* tail-kernel launches issued so far (option "fused_tail"; a captured chain counts once, at capture) */
-int dr_tail_launches(dr_engine* e, int64_t* count);
+/*
+ * How this engine launches the residual layers, and what has happened to that decision - the record a measurement
+ * must check (bench.py refuses to print a line when `fallbacks` or `yields` moved during its timed region):
+ *   mode          DR_MODE_* of the most recently planned network evaluation (a captured chain: at capture)
+ *   fused_enabled the current value of option "fused_stack" (0 while the engine runs per-phase launches after a
+ *                 time-out or a yield)
+ *   fallbacks     time-outs dr_finish has detected and healed (each switched the engine to per-phase launches)
+ *   yields        times the engine gave up fusing BEFORE launching because another process was found computing on
+ *                 its GPU (csrc/tenants.h); same results, one launch per phase from then on
+ *   rearms        times fused launches were switched back on (after "fused_rearm" clean chains behind a time-out, or
+ *                 two clean looks behind a yield)
+ *   stack_launches / tail_launches   persistent launches issued so far (a captured chain counts once, at capture)
+ */
+enum { DR_MODE_NONE = 0, DR_MODE_PER_PHASE = 1, DR_MODE_FUSED_STACK = 2, DR_MODE_FUSED_STACK_TAIL = 3 };
+typedef struct dr_launch_info {
+    int32_t mode;
+    int32_t fused_enabled;
+    int64_t fallbacks;
+    int64_t yields;
+    int64_t rearms;
+    int64_t stack_launches;
+    int64_t tail_launches;
+} dr_launch_info;
+int dr_launch_state(dr_engine* e, dr_launch_info* out);
 
 /*
  * Roll -> notes, the scan of extract_notes_wo_velocity (task/diffusion.py:1185-1233) as the reference's
@@ -276,23 +298,6 @@ int dr_extract_x0(dr_engine* e, const float* d_x_t, const float* d_epsilon, cons
                   const float* d_sac, const float* d_s1m, int n_steps, int B, size_t per_sample, float* d_out,
                   void* stream);
 
-/* Diagnostic: the FFT stage of dr_frontend on its own - reflect padding + windowed FFT + / sqrt(sum w^2) + |.|^2
- * (torchaudio Spectrogram(center, reflect, normalized=True, power=2) = torch.stft + those two steps;
- * model/diffwave.py:635,643) - d_wav (B, L) -> d_power_out (B, L / hop + 1, n_fft / 2 + 1) row-major.  Lets a test
- * hold the FFT kernel to torch.stft directly.  n_fft must be a power of two.  Synchronises `stream`. */
-int dr_debug_stft_power(dr_engine* e, const float* d_wav, int B, int L, float* d_power_out, void* stream);
-
-/* Checker builds only (csrc compiled with -DDR_BOUNDS, tools/checked_build.sh): every hand-computed LDS address and
- * in-range buffer offset of the GEMM kernels and of the fused residual-stack kernel is compared at run time with the
- * region it must stay inside, and every tensor extent a launch will touch with the device allocation it lives in.
- * out4 = {code of the first violated check (0 = none), two details, number of violations} since the last reset.
- * A production build returns DR_ESTATE.  Synchronises the device. */
-int dr_debug_bounds(int64_t* out4, int reset);
-/* Test hook of the co-tenant detection (csrc/tenants.h): scans a KFD sysfs tree rooted at kfd_root (the real one is
- * /sys/class/kfd/kfd) for the GPU at PCI (domain, bus, device): out4 = {the driver's gpu_id or -1, processes holding a
- * compute queue on it, the sum of their cu_occupancy, 1 if the proc directory was readable}.  No engine, no GPU. */
-int dr_debug_tenants(const char* kfd_root, int pci_domain, int pci_bus, int pci_device, int64_t* out4);
-
 /* Spectrogram normalisation of the following dr_frontend calls: the mode of Normalization(0, 1, norm_args[2])
  * (model/diffwave.py:632, model/utils.py:10-32) - min-max per clip ("imagewise", the default and the released
  * configs) or per frame over the frequency bins ("framewise"). */
@@ -303,16 +308,6 @@ int dr_set_spec_norm(dr_engine* e, int mode);
 /* Select DR_PRECISION_* for subsequent dr_forward / dr_step / dr_sample calls (default F32).
  * Drops a captured chain. */
 int dr_set_precision(dr_engine* e, int mode);
-
-/* Timing of the dominant kernel (dilated conv + gate) inside dr_sample, measured with HIP events
- * on the launch stream when enabled: returns launches and total milliseconds since last reset. */
-int dr_profile_enable(dr_engine* e, int on);
-int dr_profile_read(dr_engine* e, int64_t* launches, double* total_ms, int reset);
-/* The same plus the ALGORITHMIC FLOPs of the timed launches (SURVEY.md 8d per-frame figures x the frames each
- * launch processed) and the name of the timed kernel: the dominant kernel is the fused residual-stack kernel
- * when the launch geometry allows it (below), else the dilated conv + gate kernel. */
-int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double* total_flops, char* name,
-                       size_t name_len, int reset);
 
 /*
  * Integer options (defaults in brackets).  Changing one drops a captured chain.
@@ -330,10 +325,10 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          run in the last bits (the per-phase launches split K where the fused kernel does not).
  *   "fused_stack"      [1] the residual layers of an evaluation (model/diffwave.py:678-681: 15 x ResidualBlock.forward,
  *                          :134-151) run as ONE persistent launch whenever samples x frame tiles x M tiles fits the
- *                          chip's CUs in one resident round (the BASELINE configurations 2-4 do); 0 = one launch per
+ *                          chip's CUs in one resident round (the BASELINE configurations 2-5 do: 64 / 128 / 160-frame blocks); 0 = one launch per
  *                          dilated conv and per 1x1 (bit-identical results, 2 x residual_layers launches); 2 = fuse
  *                          also launches that fill less than half the chip (tests).
- *   "fused_tail"       [1] where the evaluation is one fused launch of the 64 / 128-frame flavours, the REST of a reverse
+ *   "fused_tail"       [1] where the evaluation is one fused launch, the REST of a reverse
  *                          step is fused too (model/diffwave.py:667-668, :682-686; task/diffusion.py:953-967): skip
  *                          projection, output projection, combine + posterior update, the NEXT step's input projection
  *                          and - under classifier-free guidance - the next step's first-layer dilated conv (the same
@@ -342,42 +337,10 @@ int dr_profile_read_ex(dr_engine* e, int64_t* launches, double* total_ms, double
  *                          2 launches per reverse step instead of 6 (the first step of a chain still runs its input
  *                          projection and first-layer conv as launches of their own).  0 = separate launches
  *                          (bit-identical without split-K).
- *   "fused_stack_xcd"  [1] block mapping of that kernel: 1 = the blocks of a clip share an XCD (and its L2),
- *                          0 = one weight panel per XCD.  Performance only.
- *   "fused_stack_warm" [0] idle waves of that kernel touch the next phase's weights / conditioner tile so that
- *                          they are L2-resident when needed.  Performance only (measured: 888.6 vs 889.3 ms per
- *                          config-2 chain, i.e. nothing, and 511.6 vs 486.3 ms at config 3 - the loads it would
- *                          speed up are already hidden, and with 64-frame blocks the extra traffic hurts).
- *   "stack_fault_test" [0] test hook: the fused kernel's group barriers await one arrival more than a group has, so
- *                          the first wait runs into its spin bound (~1 s) - the launch ends, flags the time-out,
- *                          later fused launches return at once, dr_finish reports DR_ETIMEOUT and heals, and any
- *                          other call fails with DR_ETIMEOUT until dr_finish / dr_stack_status has cleared it.
- *   "stack_ticks"      [0] block 0 records s_memtime at every phase start (dr_stack_status).
- *   "tune.<field>"         A/B knobs of the tile / split-K / fused-stack planners and the launchers, PROCESS-wide (they
- *                          apply to every engine of the process from the next launch on): tune.tile (3201 / 3202 / 3203 /
- *                          3205 / 1603 / 1605 = MFMA size and frame tiles per wave; 0 = cost model), tune.pw, tune.pw_nw,
- *                          tune.pwk, tune.ksplit_max, tune.ksplit_blocks, tune.one_ks, tune.stack3, tune.stack_fl,
- *                          tune.xcd_n, tune.xcd_model, tune.pack_threads, tune.s3_eager, tune.debug_chunks - fields and
- *                          defaults: csrc/kernels.h `Tuning`.  What tools/ and the bit-identity tests pin kernel flavours
- *                          with (tools/tuning_env.py); the library reads NO environment variable.
+ * Unknown names -> DR_ENAME.  (The A/B and test knobs - "tune.*", "fused_stack_xcd", "fused_stack_warm", "stack_ticks" -
+ * are set with dr_debug_set_option, diffroll_amd_debug.h.)
  */
 int dr_set_option(dr_engine* e, const char* name, int value);
-/* Synchronises the device.  *timed_out != 0: a group barrier of the fused kernel ran into its spin bound (results
- * of that launch are invalid; never observed in a healthy run) - the counters are reset.  *launches: fused-kernel
- * launches issued so far (a captured chain counts once, when it is captured).  ticks (optional, n_ticks <= 128):
- * the phase tick marks of the last launch recorded with "stack_ticks". */
-int dr_stack_status(dr_engine* e, int32_t* timed_out, int64_t* launches, int64_t* ticks, int n_ticks);
-
-/* Standalone launch of the fused dilated-conv+gate kernel of layer `layer` on the engine's
- * workspace activations (for micro-benchmarks / roofline): returns 0. */
-int dr_bench_layer(dr_engine* e, int layer, int NB, int T, int t, int n_cond, void* stream);
-/* Same for the 1x1 output projection + residual/skip kernel of layer `layer` (in place on the
- * workspace: repeated launches keep rescaling h, which is harmless for timing). */
-int dr_bench_pointwise(dr_engine* e, int layer, int NB, int T, void* stream);
-/* s_memtime ticks (shader clock) block 0 of the last dr_bench_layer launch spent in its K loop / in
- * total: with the wall time this gives the effective clock the kernel ran at. */
-int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks);
-
 /*
  * Multi-GPU: the path shards by clips - one process per GPU, every rank runs its contiguous shard of
  * the batch with dr_sample (first_sample = the shard's global offset, so Philox noise does not depend on the world
@@ -386,17 +349,23 @@ int dr_debug_ticks(dr_engine* e, int64_t* loop_ticks, int64_t* block_ticks);
  * The reference reaches N GPUs through Lightning's Trainer(gpus=N) (sampling.py:70) and never gathers.
  *   dr_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank by any side channel
  *   dr_comm_create      every rank, collectively: ncclCommInitRank on `device`
+ *   dr_comm_info        ranks / rank of a communicator and the version code of the loaded librccl (any pointer may be
+ *                       NULL; c == NULL: the version alone)
  *   dr_gather           d_shard (B_local, T, 88) of every rank -> d_full (n_ranks * B_local, T, 88), rank-major, on
  *                       `stream` (ncclAllGather; equal B_local on all ranks - pad uneven shards, see
- *                       diffroll_amd/distributed.py).  `e` may be NULL.
+ *                       diffroll_amd/distributed.py).  `e` may be NULL.  SYNCHRONOUS, and the verdict is COLLECTIVE: behind the
+ *                       rolls every rank also gathers one status word (0 = my shard is valid, 1 = it came out of a fused
+ *                       launch that timed out: dr_pending_timeout), and EVERY rank returns DR_ETIMEOUT when any shard was
+ *                       invalid - nobody is handed a d_full that holds a bad shard together with DR_OK.  After
+ *                       DR_ETIMEOUT: the rank(s) whose dr_finish also reports it recompute their shard, then all ranks
+ *                       gather again.
  * Errors of these functions: dr_comm_last_error().
  */
 typedef struct dr_comm dr_comm;
-int dr_rccl_version(int* version);
 int dr_comm_unique_id(char* id_out /* 128 bytes */);
 int dr_comm_create(dr_comm** out, const char* id /* 128 bytes */, int n_ranks, int rank, int device);
 void dr_comm_destroy(dr_comm* c);
-int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank);
+int dr_comm_info(const dr_comm* c, int* n_ranks, int* rank, int* rccl_version);
 const char* dr_comm_last_error(void);
 int dr_gather(dr_engine* e, dr_comm* comm, const float* d_shard, float* d_full, int B_local, int T, void* stream);
 

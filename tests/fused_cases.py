@@ -39,6 +39,16 @@ CASES = {
         (384, 2, 9, 20, 129, "ddpm_x0"),            # 6 M tiles (residual / skip halves split inside no tile), ragged 2nd tile
         (512, 2, 9, 32, 125, "cfdg_ddpm_x0"),       # 64 evaluations: two fused launches (all conditional / all unconditional)
     ],
+    5: [  # 160-frame blocks (the 640-frame geometries: 4 tiles per clip; blocked accumulation only)
+        (512, 3, 9, 4, 640, "cfdg_ddpm_x0"),        # the reference's shipping geometry: 8 evaluations x 4 tiles x 8 M tiles = 256 blocks
+        (512, 2, 15, 4, 640, "cfdg_ddpm_x0"),       # BASELINE config 5 per GPU: k = 15, halo 56 frames across the 4 tiles
+        (512, 2, 9, 8, 320, "generation_ddpm_x0"),  # 2 tiles per clip, 8 groups of 16 blocks
+        (128, 3, 15, 5, 161, "ddpm_x0"),            # ragged: the second tile holds ONE frame
+        (192, 3, 9, 4, 200, "cfdg_ddpm_x0"),        # 3 M tiles: tile 1 straddles the residual / skip halves; 40-frame second tile
+        (64, 2, 3, 8, 100, "generation_ddpm_x0"),   # one part-filled tile per clip (frames 100..159 do not exist)
+        (384, 2, 9, 3, 500, "ddpm_x0"),             # 6 M tiles x 4 tiles; the last tile holds 20 frames
+        (512, 2, 9, 16, 640, "generation_ddpm_x0"), # 16 evaluations x 32 blocks: two fused launches of 8 samples
+    ],
 }
 # the split-bf16 flavours of the fused kernel (precision="bf16x3"; channel counts that are multiples of 128)
 CASES_S3 = {

@@ -18,19 +18,60 @@ def lib():
     return _cabi.load_library()
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+def header_functions(name="diffroll_amd.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(dr_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree(lib):
+    """Both headers: include/diffroll_amd.h is the boundary (<= 30 functions, SURVEY.md 8b asks for about nine), and
+    include/diffroll_amd_debug.h the lab (measurement / checker / test entry points of the same library).  The ctypes
+    binding declares exactly these, the library exports them, and nothing ELSE that starts with dr_."""
+    import subprocess
     from diffroll_amd import _cabi
     declared = header_functions()
     assert declared, "no functions parsed from the header"
     assert sorted(_cabi.EXPORTS) == declared
-    for name in declared:
-        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert len(declared) <= 30, len(declared)
+    lab = header_functions("diffroll_amd_debug.h")
+    assert sorted(_cabi.DEBUG_EXPORTS) == lab and not set(lab) & set(declared)
+    for name in declared + lab:
+        assert hasattr(lib, name), f"{name} declared in a header but not exported"
+    # the boundary header holds no lab vocabulary
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for word in ("dr_debug_", "dr_bench_", "dr_profile_", "dr_stack_status", "dr_cold_times"):
+        assert word not in code, word                     # (comments may point at the lab header)
+    assert "stack_fault_test" not in text
+    nm = subprocess.run(["nm", "-D", "--defined-only", _cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("dr_")})
+    assert exported == sorted(declared + lab), set(exported) ^ set(declared + lab)
+
+
+def test_production_library_has_no_fault_injection():
+    """the test hook of the time-out path ("stack_fault_test": barriers that wait for one arrival too
+    many) is compiled into the "hook" variant only (-DDR_FAULT_HOOK) - the shipped library does not contain the string."""
+    import subprocess
+    from diffroll_amd import build
+    strs = subprocess.run(["strings", build.build(verbose=False)], capture_output=True, text=True, check=True).stdout
+    assert "stack_fault_test" not in strs
+    assert "-DDR_FAULT_HOOK" in build.VARIANTS["hook"]["flags"]
+    hook = build.variant_path("hook")
+    if os.path.exists(hook):      # (built by __graft_entry__.build(); a CPU box without it skips the positive half)
+        assert "stack_fault_test" in subprocess.run(["strings", hook], capture_output=True, text=True, check=True).stdout
+
+
+def test_launch_info_struct_layout_matches_header():
+    from diffroll_amd import _cabi
+    text = open(os.path.join(ROOT, "include", "diffroll_amd.h")).read()
+    body = re.search(r"typedef struct dr_launch_info \{(.*?)\} dr_launch_info;", text, flags=re.S).group(1)
+    fields = re.findall(r"\b(int32_t|int64_t)\s+(\w+);", body)
+    assert [f[1] for f in fields] == [f[0] for f in _cabi.DrLaunchInfo._fields_]
+    for (ctype, _), (_, pyt) in zip(fields, _cabi.DrLaunchInfo._fields_):
+        assert pyt is (C.c_int32 if ctype == "int32_t" else C.c_int64)
+    modes = dict(re.findall(r"(DR_MODE_\w+) = (\d)", text))
+    assert {int(v) for v in modes.values()} == set(_cabi.MODES) and _cabi.MODES[int(modes["DR_MODE_FUSED_STACK_TAIL"])] == "fused_stack+tail"
 
 
 def test_abi_version(lib):
@@ -120,8 +161,10 @@ def test_comm_entry_points_fail_cleanly_without_a_gpu():
     import torch
     lib = _cabi.load_library()
     v = C.c_int(0)
-    rc = lib.dr_rccl_version(C.byref(v))
+    rc = lib.dr_comm_info(None, None, None, C.byref(v))        # no communicator: the version of the loaded librccl alone
     assert (rc == 0 and v.value > 20000) or (rc != 0 and lib.dr_comm_last_error())
+    n = C.c_int(0)
+    assert lib.dr_comm_info(None, C.byref(n), None, None) == _cabi.DR_EINVAL
     if not torch.cuda.is_available():
         h = C.c_void_p()
         assert lib.dr_comm_create(C.byref(h), b"\0" * 128, 1, 0, 0) == _cabi.DR_EINVAL
@@ -136,8 +179,9 @@ def test_round3_entry_points_reject_bad_calls_without_a_gpu(lib):
     from diffroll_amd import _cabi
     assert lib.dr_finish(None, None) == _cabi.DR_EINVAL
     assert lib.dr_sample_checked(None, 1, None, None, 1, 1, 0.5, 0, 0, 1, None, None) == _cabi.DR_EINVAL
-    n = C.c_int64(7)
-    assert lib.dr_stack_fallbacks(None, C.byref(n)) == _cabi.DR_EINVAL and lib.dr_tail_launches(None, C.byref(n)) == _cabi.DR_EINVAL
+    info = _cabi.DrLaunchInfo()
+    assert lib.dr_launch_state(None, C.byref(info)) == _cabi.DR_EINVAL and lib.dr_launch_state(None, None) == _cabi.DR_EINVAL
+    assert lib.dr_set_option(None, b"fused_stack", 1) == _cabi.DR_EINVAL and lib.dr_debug_set_option(None, b"tune.tile", 0) == _cabi.DR_EINVAL
     assert lib.dr_debug_stft_power(None, None, 1, 4096, None, None) == _cabi.DR_EINVAL
     out = (C.c_int64 * 4)()
     if "bounds" not in os.path.basename(_cabi.LIB_PATH):
@@ -152,7 +196,7 @@ def test_round3_entry_points_reject_bad_calls_without_a_gpu(lib):
 def test_checker_build_variants_are_declared():
     """tools/checked_build.sh drives diffroll_amd.build's variants: the -DDR_BOUNDS kernels and the ASan/UBSan host."""
     from diffroll_amd import build
-    assert {"bounds", "asan", "ubsan"} <= set(build.VARIANTS)          # (+ measurement builds)
+    assert {"bounds", "asan", "ubsan", "hook"} <= set(build.VARIANTS)          # (+ measurement builds)
     assert "-DDR_BOUNDS" in build.VARIANTS["bounds"]["flags"]
     assert any("-fsanitize=address" in f for f in build.VARIANTS["asan"]["flags"])
     assert build.variant_path("bounds").endswith("libdiffroll_amd_bounds.so")

@@ -159,6 +159,15 @@ def test_scale_record_flags_a_cell_that_ran_with_fewer_ranks_than_asked(monkeypa
     table["config2/gpus2"] = cell(2, 190.0, 1)            # asked for 2, the group had 1
     rec = st.scale_record(table, [1, 2, 4], [2])
     assert not rec["ok"] and "asked for 2 ranks" in rec["problems"][0]
+    # ranks that did not all launch the same kernels (one of them yielded to per-phase launches: dr_launch_state) are no
+    # scaling point either - bench.py refuses to print such a line, and a record that carries one anyway is flagged
+    good = dict(cell(2, 190.0, 2), per_rank_launch_mode=["fused_stack+tail"] * 2, launch_mode="fused_stack+tail", fused_yields=0, fused_fallbacks=0)
+    table["config2/gpus2"] = good
+    rec = st.scale_record(table, [1, 2, 4], [2])
+    assert rec["ok"] and rec["configs"]["2"][1]["per_rank_launch_mode"] == ["fused_stack+tail"] * 2
+    table["config2/gpus2"] = dict(good, per_rank_launch_mode=["fused_stack+tail", "per_phase"], launch_mode="mixed", fused_yields=1)
+    rec = st.scale_record(table, [1, 2, 4], [2])
+    assert not rec["ok"] and "did not all run the same kernels" in rec["problems"][0]
 
 
 def test_share_gpu_mode_switches_the_group_to_gloo_and_host_tensors(monkeypatch):

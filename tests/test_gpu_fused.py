@@ -36,11 +36,12 @@ def _run_both(m, fn, xcds=(1, 0)):
     return ref, outs
 
 
-@pytest.mark.parametrize("ni", ["1", "2", "2b", "1s", "2s", "2sb"])
+@pytest.mark.parametrize("ni", ["1", "2", "2b", "5b", "1s", "2s", "2sb"])
 def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     """All cases of tests/fused_cases.py for one block flavour, in a child process whose per-phase kernels are
     pinned to the flavours the fused kernel is built from (tune.* options, tools/tuning_env.py).  "2b" = the
-    128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations);
+    128-frame flavour with blocked accumulation requested (option blocked_accumulation = 2: other instantiations); "5b" = the
+    160-frame flavour of the 640-frame geometries (blocked accumulation only; per-phase twin: gemm_kernel<5> + pw_kernel<5>);
     "1s" / "2s" / "2sb" = the split-bf16 flavours (precision="bf16x3": S3 hand-offs, LDS-staged 1x1 phases, no tail
     kernel; "2sb": 128-frame blocks with blocked accumulation)."""
     import json, os, subprocess, sys
@@ -49,7 +50,7 @@ def test_fused_stack_is_bit_identical_to_per_phase_launches(ni):
     s3 = "s" in ni
     ni = int(ni[0])
     from tools import tuning_env
-    env = tuning_env.env_with(tune__ksplit_max=1, tune__tile=3200 + ni, tune__pw_nw=2 * ni, tune__stack_fl=ni,
+    env = tuning_env.env_with(tune__ksplit_max=1, tune__tile=3200 + ni, tune__pw_nw=5 if ni == 5 else 2 * ni, tune__stack_fl=ni,
                               blocked_accumulation=2 if blocked else 1)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fused_cases.py"), str(ni)] + (["bf16x3"] if s3 else []), env=env,
                        capture_output=True, text=True, timeout=900)

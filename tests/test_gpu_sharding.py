@@ -131,6 +131,8 @@ def test_one_rank_under_torch_distributed_run():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["dist"]["ranks_seen"] == 1 and j["dist"]["backend"] == "nccl", j["dist"]
     assert j["value"] > 0 and j["config"]["baseline_config"] == 1
+    # what the engine launched is part of the line (dr_launch_state): a single clip runs one launch per phase, nobody yielded
+    assert j["fused_yields"] == 0 and j["fused_fallbacks"] == 0 and j["per_rank_launch_mode"] == ["per_phase"] and j["launch_mode"] == "per_phase"
 
 
 def test_bench_refuses_more_gpus_than_visible():
@@ -253,6 +255,99 @@ def test_two_rank_bench_path_executes_on_one_gpu():
     # value = BOTH ranks' frames over the max-over-ranks time
     assert abs(j["value"] - 2 * 1 * 125 * 1e3 / j["ms_per_step"]) <= 0.01 * j["value"]
     assert j["gather_us"] > 0
+    assert j["per_rank_launch_mode"] == ["per_phase", "per_phase"]      # one entry per rank (--share-gpu asks for per-phase launches)
+
+
+def _fake_kfd_tree(root, busy):
+    """A copy of this box's KFD topology with a made-up process list: every GPU has two queue holders, one of them computing
+    (busy) or none.  Returns False where the real tree is not readable (no sysfs in the container)."""
+    real = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(real):
+        return False
+    gids = []
+    for nd in os.listdir(real):
+        try:
+            gid = open(f"{real}/{nd}/gpu_id").read().strip()
+            props = open(f"{real}/{nd}/properties").read()
+        except OSError:
+            return False
+        d = os.path.join(root, "topology", "nodes", nd)
+        os.makedirs(d)
+        open(os.path.join(d, "gpu_id"), "w").write(gid + "\n")
+        open(os.path.join(d, "properties"), "w").write(props)
+        if gid != "0":
+            gids.append(gid)
+    for pid, occ in ((4001, 0), (4002, 133 if busy else 0)):
+        for n, gid in enumerate(gids):
+            qd = os.path.join(root, "proc", str(pid), "queues", str(n))
+            os.makedirs(qd)
+            open(os.path.join(qd, "gpuid"), "w").write(gid + "\n")
+            sd = os.path.join(root, "proc", str(pid), f"stats_{gid}")
+            os.makedirs(sd)
+            open(os.path.join(sd, "cu_occupancy"), "w").write(f"{occ}\n")
+    return bool(gids)
+
+
+def test_engine_yields_to_a_busy_co_tenant_and_comes_back(tmp_path):
+    """VERDICT r5 item 1 / ADVICE r5: a yield is VISIBLE (dr_launch_state: yields, mode, fused_enabled) and RECOVERABLE.
+    The engine is shown a KFD process list in which another process computes on its GPU (dr_debug_kfd_root): it yields at
+    creation and samples with one launch per phase; shown a list in which the co-holder idles, two looks in front of later
+    chains switch the fused launches back on.  Same rolls all along."""
+    import time
+    from diffroll_amd import _cabi
+    busy, idle = str(tmp_path / "busy"), str(tmp_path / "idle")
+    if not (_fake_kfd_tree(busy, True) and _fake_kfd_tree(idle, False)):
+        pytest.skip("no readable /sys/class/kfd/kfd/topology in this container")
+    lib = _cabi.load_library()
+    lib.dr_debug_kfd_root(busy.encode())
+    try:
+        hp, p, m = _model(layers=3, steps=8, C=512)
+        torch.manual_seed(11)
+        B, Tn = 16, 125                                   # 32 evaluations x 8 M tiles: the fused kernels' own geometry
+        wav = 0.1 * torch.randn(B, Tn * 512)
+        x = torch.randn(B, 1, Tn, 88)
+        eng = m.engine
+        st = eng.launch_state()
+        assert st["yields"] == 1 and st["fused_enabled"] == 0 and eng.yields == 1, st
+        a = m.sample(x, wav, seed=2)[0]
+        st = eng.launch_state()
+        assert st["mode"] == "per_phase" and st["yields"] == 1 and st["fallbacks"] == 0 and st["rearms"] == 0, st
+        time.sleep(0.3)
+        m.sample(x, wav, seed=2)                          # a look that still finds the tenant computing: nothing changes
+        assert eng.launch_state()["fused_enabled"] == 0
+        lib.dr_debug_kfd_root(idle.encode())              # the tenant has stopped computing (it still holds its queue)
+        for _ in range(2):
+            time.sleep(0.3)
+            m.sample(x, wav, seed=2)
+        st = eng.launch_state()
+        assert st["rearms"] == 1 and st["fused_enabled"] != 0, st
+        b = m.sample(x, wav, seed=2)[0]
+        st = eng.launch_state()
+        assert st["mode"] == "fused_stack+tail" and st["yields"] == 1 and st["fallbacks"] == 0, st
+        assert float((a - b).abs().max()) <= ATOL_SHARD
+    finally:
+        lib.dr_debug_kfd_root(None)
+
+
+def test_bench_refuses_to_print_a_line_when_the_engine_yielded(tmp_path):
+    """... and a yield is FATAL for a measurement: bench.py, shown the same busy co-tenant (DR_BENCH_FAKE_KFD), exits
+    non-zero without a JSON line instead of reporting per-phase launches as the engine's throughput - the one way the
+    first 8-GPU scaling run could have come out wrong without anything failing."""
+    busy = str(tmp_path / "busy")
+    if not _fake_kfd_tree(busy, True):
+        pytest.skip("no readable /sys/class/kfd/kfd/topology in this container")
+    env = _clean_env()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+           "--no-split", "--no-roofline", "--no-cold-start"]
+    r = subprocess.run(cmd, env=dict(env, DR_BENCH_FAKE_KFD=busy), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode != 0 and '"metric"' not in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "yield" in r.stderr and "no benchmark line" in r.stderr, r.stderr[-2000:]
+    # the same command on the real process list: a line, with the record of what was launched
+    import json
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    assert j["fused_yields"] == 0 and j["fused_fallbacks"] == 0 and j["launch_mode"] == "fused_stack+tail", j
 
 
 def test_scale_table_emits_a_scale_record_for_one_and_two_ranks(tmp_path):

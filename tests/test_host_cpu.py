@@ -249,6 +249,57 @@ def test_checkpoint_with_omegaconf_shaped_hparams_loads_without_omegaconf(tmp_pa
         assert torch.equal(m2.state_dict()[k], v)
 
 
+def test_checkpoint_that_names_os_system_loads_to_a_stub_and_executes_nothing(tmp_path):
+    """reading a checkpoint is safe by default.  A pickle that names os.system (the classic
+    __reduce__ payload) - in the hyper-parameters, or in place of a weight - is read by the allow-listing unpickler: the
+    global becomes an inert stand-in, NOTHING runs; trust=True is the explicit way to get Lightning's full unpickle, and with
+    it the payload does run (which is the point of not doing that by default)."""
+    import os
+    from diffroll_amd import ClassifierFreeDiffRoll
+    from diffroll_amd.checkpoint import TolerantUnpickler, load_checkpoint
+    marker = str(tmp_path / "pwned")
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {marker}",))
+
+    m = make(kernel_size=9)
+    hp = dict(residual_channels=32, unconditional=False, condition="fixed", n_mels=229, norm_args=[0, 1, "imagewise"],
+              residual_layers=3, kernel_size=9, dilation_base=2, dilation_bound=4, timesteps=8,
+              spec_args=dict(sample_rate=16000, n_fft=2048, hop_length=512, n_mels=229, f_min=0, f_max=8000, center=True,
+                             normalized=True, pad_mode="reflect"),
+              sampling=dict(type="cfdg_ddpm_x0", w=0), training=dict(mode="x_0"), callbacks=Evil())
+    path = str(tmp_path / "evil.ckpt")
+    torch.save({"state_dict": m.state_dict(), "hyper_parameters": hp}, path)
+    ck = load_checkpoint(path)
+    assert not os.path.exists(marker), "loading a checkpoint executed code"
+    assert ck["hyper_parameters"]["callbacks"] == f"touch {marker}"       # the stand-in recorded its argument: data, not a call
+    assert ck["hyper_parameters"]["kernel_size"] == 9
+    m2 = ClassifierFreeDiffRoll.load_from_checkpoint(path)
+    assert not os.path.exists(marker)
+    for k, v in m.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v)
+    # the allow-list is about names, not about what is installed: builtins.eval / getattr / torch.load are stand-ins too
+    import io
+    import pickle
+    for mod, name in (("builtins", "eval"), ("builtins", "getattr"), ("os", "system"), ("torch", "load"), ("subprocess", "Popen"),
+                      ("torch.serialization", "load"), ("numpy", "load")):
+        got = TolerantUnpickler(io.BytesIO(b"")).find_class(mod, name)
+        assert got.__mro__[1].__name__ == "_Stub", (mod, name)
+    ok = TolerantUnpickler(io.BytesIO(pickle.dumps(0))).find_class("collections", "OrderedDict")
+    assert ok.__name__ == "OrderedDict" and TolerantUnpickler(io.BytesIO(b"")).find_class("torch", "float32") is torch.float32
+    # a payload in place of a WEIGHT is refused (a stand-in is not a tensor)
+    sd = dict(m.state_dict())
+    sd["input_projection.bias"] = Evil()
+    torch.save({"state_dict": sd, "hyper_parameters": {}}, path)
+    with pytest.raises(ValueError, match="not tensors"):
+        load_checkpoint(path)
+    assert not os.path.exists(marker)
+    with pytest.raises(ValueError, match="not tensors"):  # the full unpickle: the payload RUNS (os.system returned an int
+        load_checkpoint(path, trust=True)                 # where a weight should be - still no tensor)
+    assert os.path.exists(marker)
+
+
 def test_checkpoint_interpolations_resolve_against_the_root(tmp_path):
     """Real reference checkpoints carry spec_args = cfg.spec.args with `sample_rate: ${sampling_rate}` and
     `hop_length: ${hop_length}` (config/spec/mel.yaml, train_spec_roll.py:30): the pickled value nodes hold those

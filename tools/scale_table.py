@@ -10,7 +10,8 @@ sampling.py:70), and so does `bench.py --gpus N` (it starts its own ranks).
 time, the gather on its own, ranks_seen, backend, the RCCL version (also as RCCL prints it: NCCL_DEBUG=VERSION is set for
 every run and its banner line is kept) and the weak-scaling efficiency against N = 1.  The exit code is non-zero when any
 cell that ran saw a number of ranks different from the N it was asked for - a run that silently fell back to fewer
-processes must not pass for a scaling point.
+processes must not pass for a scaling point - or whose ranks did not all launch the same kernels (per_rank_launch_mode,
+fused_yields, fused_fallbacks of the bench line: dr_launch_state).
 
 Each cell is one `python bench.py --gpus N --config C --no-split --no-cpu-baseline --no-roofline` run; a world size
 the node cannot serve (fewer visible devices) is reported as such and skipped, so the same command works on a 1-GPU
@@ -69,6 +70,13 @@ def scale_record(table, gpus, configs):
             if seen != n or j.get("n_gpus") != n:
                 rec["ok"] = False
                 rec["problems"].append(f"config {c}: asked for {n} ranks, the job saw {seen} (n_gpus {j.get('n_gpus')})")
+            pm = j.get("per_rank_launch_mode") or []
+            if len(set(pm)) > 1 or j.get("fused_yields") or j.get("fused_fallbacks"):
+                # (bench.py refuses to print such a line outside --share-gpu; a record that carries one anyway is not a point)
+                if not d.get("share_gpu"):
+                    rec["ok"] = False
+                    rec["problems"].append(f"config {c}, {n} ranks: launch modes {pm}, yields {j.get('fused_yields')}, "
+                                           f"fallbacks {j.get('fused_fallbacks')} - the ranks did not all run the same kernels")
             if base is None and n == 1:
                 base = j["value"]
             pr = j.get("per_rank_ms_per_step", {})
@@ -77,6 +85,8 @@ def scale_record(table, gpus, configs):
                          "ranks_seen": seen, "backend": d.get("backend"), "rccl_version": d.get("rccl_version"),
                          "rccl_banner": j.get("_rccl_banner"), "launcher": d.get("launcher"), "scaling": j.get("scaling"),
                          "share_gpu": bool(d.get("share_gpu", False)), "per_rank_ms_all": pr.get("all"),
+                         "launch_mode": j.get("launch_mode"), "per_rank_launch_mode": pm, "fused_yields": j.get("fused_yields"),
+                         "fused_fallbacks": j.get("fused_fallbacks"),
                          "efficiency_vs_n1": (j["value"] / (n * base)) if base else None, "wall_s": j["_wall_s"],
                          "workload": j.get("config", {}).get("workload")})
         rec["configs"][str(c)] = rows
