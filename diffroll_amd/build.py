@@ -42,19 +42,12 @@ VARIANTS = {
     #   asan:   the HOST side (pack / plan / abi / debug_abi / comm .hip: packing, tables, C-ABI marshalling) under AddressSanitizer +
     #           UndefinedBehaviorSanitizer; device code is compiled as usual (-fno-gpu-sanitize)
     "bounds": dict(flags=["-DDR_BOUNDS"], link=[]),
-    "ablate1": dict(flags=["-DDR_ABLATE=1", "-DDR_FOLD=0"], link=[]),  # measurement build, WRONG results: the conv K loop loads no weight fragments
-    "ablate9": dict(flags=["-DDR_ABLATE=9", "-DDR_FOLD=0"], link=[]),   # measurement build, WRONG results: the producers stage nothing
-    # A/B builds of the conv K loop (round 4): the rounds 1-3 loop (one chain per output, two weight-fragment sets) /
-    # blocked accumulation off, in-place fragments on / blocked accumulation with two fragment sets
-    # litmus builds (WRONG on purpose): the hand-over without its vmcnt wait / hand-offs without write-through stores
     # test build of the time-out path: the ONLY library that knows the option "stack_fault_test" (the persistent kernels' group
     # barriers can be told to wait for one arrival too many); correct results otherwise.  tests/hook_cases.py runs against it
     "hook": dict(flags=["-DDR_FAULT_HOOK"], link=[]),
+    # litmus builds (WRONG on purpose): the hand-over without its vmcnt wait / hand-offs without write-through stores
     "fault1": dict(flags=["-DDR_FAULT=1"], link=[]),
     "fault2": dict(flags=["-DDR_FAULT=2"], link=[]),
-    "r3loop": dict(flags=["-DDR_FOLD=0", "-DDR_AINPLACE=0"], link=[]),
-    "nofold": dict(flags=["-DDR_FOLD=0"], link=[]),
-    "twosets": dict(flags=["-DDR_AINPLACE=0"], link=[]),
     "asan": dict(flags=["-O1", "-g", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-fno-omit-frame-pointer"],
                  link=["-fsanitize=address,undefined", "-shared-libsan"]),
     #   ubsan:  the host side under UndefinedBehaviorSanitizer alone (-fno-sanitize-recover: the first finding aborts).

@@ -14,28 +14,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DR_DEVINL __device__ __forceinline__
 
-// DR_ABLATE (compile-time, measurement builds only; results are WRONG when non-zero):
-//   1 = no A-fragment prefetch in the K loop, 2 = (S3 path) A fragments always from slab 0 (cache-hot),
-//   9 = producers do no loads / LDS writes (barriers only)
-#ifndef DR_ABLATE
-#define DR_ABLATE 0
-#endif
-// DR_AINPLACE (compile-time A/B switch, default on): the 128-frame flavours of gemm_body refresh their weight fragments
-// in place (one register set) instead of alternating between two sets - see gemm_body.h
-#ifndef DR_AINPLACE
-#define DR_AINPLACE 1
-#endif
 // DR_FAULT (compile-time, LITMUS builds only - results are WRONG on purpose; tests/test_gpu_fused.py, tools/xcd_stress.py):
 //   1 = the producers' LDS-DMA hand-over barrier without its s_waitcnt vmcnt(0) (the round-3 race: consumers may read the
 //       buffer's previous occupant),  2 = the tensors handed to other workgroups stored PLAIN whatever the placement
 //       (no sc1 write-through: a group spread over several XCDs then reads stale lines / stale memory)
 #ifndef DR_FAULT
 #define DR_FAULT 0
-#endif
-// DR_FOLD (compile-time A/B switch, default on): blocked accumulation in gemm_body (0 = one fp32 chain per output over
-// all of K, the rounds 1-3 numerics)
-#ifndef DR_FOLD
-#define DR_FOLD 1
 #endif
 
 // DR_BOUNDS (compile-time, checker builds only: tools/checked_build.sh): every hand-computed LDS address and every

@@ -159,9 +159,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(Rs + pl * BN + seg * 64), 16, voff, 0, 0, COH ? 16 : 0);
             }
         }
-#if DR_ABLATE != 9
         issue(c0);
-#endif
         for (int chunk = c0; chunk < c1; ++chunk) {
             // hand-over #chunk: this wave's DMA of tile #chunk must have LANDED before the barrier releases the
             // consumers - barriers do not drain VMEM, and hipcc does not reliably insert the wait for a
@@ -176,9 +174,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #else                       // litmus build 1: the hand-over WITHOUT the wait - a bare s_barrier, so that hipcc's own fence
             __builtin_amdgcn_s_barrier();       // handling cannot put it back (which kernels of rounds 1-2 had it was luck)
 #endif
-#if DR_ABLATE != 9
             if (chunk + 1 < c1) issue(chunk + 1);
-#endif
         }
         return;
     }
@@ -203,7 +199,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
 #pragma unroll
         for (int e = 0; e < 16; ++e) outer[ni][e] = 0.f;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr bool FOLD = DR_FOLD && FOLDP && EPI == EPI_GATE;
+    constexpr bool FOLD = FOLDP && EPI == EPI_GATE;
     auto fold = [&]() {
         if constexpr (FOLD) {
 #pragma unroll
@@ -234,20 +230,13 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
             A12 o;
 #pragma unroll
             for (int gp = 0; gp < 6; ++gp) {
-#if DR_ABLATE == 2          // measurement build: always the same slab (L1-hot A loads)
-                const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, gp * 4096, 0);
-#else
                 DR_CHECK(slab >= 0 && wvo + slab * 24576 + gp * 4096 + 16 <= NS * 24576, 103, slab, NS);
                 const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 24576 + gp * 4096, 0);
-#endif
                 o.v[gp * 2] = make_uint4(u.x, u.y, u.z, u.w);
             }
             return o;
         };
         A12 wA = load_a3(c0 * KS * a.taps), wB;
-#if DR_ABLATE == 1
-        wB = wA;
-#endif
         const int cen = (a.taps - 1) >> 1;
         const int per_chunk = a.taps * KS;
         const uint4* Xs3 = reinterpret_cast<const uint4*>(Xs);
@@ -294,19 +283,13 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         auto step = [&](auto ROLE, auto FIRST, int slab, int chunk, int q) {
             constexpr bool kB = decltype(ROLE)::value;
             const uint4* Xb = xaddr(chunk, q);
-#if DR_ABLATE != 1          // measurement build 1: no A loads at all
             if constexpr (kB) wA = load_a3(min(slab + 1, NS - 1));
             else wB = load_a3(min(slab + 1, NS - 1));
-#endif
             b1 = rd3(Xb, 1);
             mma6(FIRST, kB ? wB.v[0] : wA.v[0], kB ? wB.v[2] : wA.v[2], kB ? wB.v[4] : wA.v[4], b0);
             b0 = rd3(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
             mma6(std::false_type{}, kB ? wB.v[6] : wA.v[6], kB ? wB.v[8] : wA.v[8], kB ? wB.v[10] : wA.v[10], b1);
-#if DR_ABLATE == 1
-            sgb_mix<3 * NW, 0>();
-#else
             sgb_mix<3 * NW, 6>();           // + the 6 A-fragment loads of the next step, one per MFMA pair
-#endif
             sgb_mix<3 * NW, 0>();
         };
         using T_ = std::true_type;
@@ -349,9 +332,6 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     static_assert(MI == 1, "one 32-row MFMA tile per consumer wave");
 
     A8 wA = load_a(c0 * KS * a.taps), wB;
-#if DR_ABLATE == 1
-    wB = wA;
-#endif
     const int cen = (a.taps - 1) >> 1;
 
     // B fragments of one 8-channel group: NW float4 (one per 32-frame MFMA tile), conflict-free ds_read_b128
@@ -396,10 +376,8 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     auto step = [&](auto ROLE, auto FIRST, int slab, int chunk, int q) {
         constexpr bool kB = decltype(ROLE)::value;
         const float4* Xb = xaddr(chunk, q);
-#if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop (both sets keep the first fragments)
         if constexpr (kB) wA = load_a(min(slab + 1, NS - 1));
         else wB = load_a(min(slab + 1, NS - 1));
-#endif
         b1 = rd(Xb, 1);
         mma4(FIRST, kB ? wB.v[0] : wA.v[0], b0);
         b0 = rd(Xb, 2);
@@ -422,7 +400,7 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
     // next step's group g right behind the group's last MFMA (one buffer load per group: prefetch distance three
     // groups = 48 MFMAs) - ONE fragment set instead of two, which is what lets the second accumulator set of the
     // blocked accumulation (64 registers at NW = 4) live in the K loop without spilling; no roles, no per-chunk copy.
-    constexpr bool AINP = DR_AINPLACE && (NI == 2 || NI == 5) && FOLD;
+    constexpr bool AINP = (NI == 2 || NI == 5) && FOLD;
     auto load_ag = [&](int slab, int g) -> float4 {
         DR_CHECK(slab >= 0 && wvo + slab * 16384 + g * 4096 + 16 <= NS * 16384, 112, slab, NS);
         const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvo, slab * 16384 + g * 4096, 0);
@@ -433,26 +411,16 @@ DR_DEVINL void gemm_body(const GemmArgs& a, char* smem, const int mt, const int 
         const int nx = min(slab + 1, NS - 1);
         b1 = rd(Xb, 1);
         mma4(FIRST, wA.v[0], b0);
-#if DR_ABLATE != 1          // measurement build 1: no A loads in the K loop
         wA.v[0] = load_ag(nx, 0);
-#endif
         b0 = rd(Xb, 2);
         mma4(F_{}, wA.v[2], b1);
-#if DR_ABLATE != 1
         wA.v[2] = load_ag(nx, 1);
-#endif
         b1 = rd(Xb, 3);
         mma4(F_{}, wA.v[4], b0);
-#if DR_ABLATE != 1
         wA.v[4] = load_ag(nx, 2);
-#endif
         b0 = rd(xaddr(chunk, min(q + 1, per_chunk - 1)), 0);
         mma4(F_{}, wA.v[6], b1);
-#if DR_ABLATE != 1
         wA.v[6] = load_ag(nx, 3);
-#else
-        (void)nx;
-#endif
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();
         sgb<0x100, NW>(); sgb<0x8, 4 * NW>(); sgb<0x20, 1>();

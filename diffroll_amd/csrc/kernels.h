@@ -144,7 +144,7 @@ size_t gemm_lds_bytes(int NI, int KS, int taps, int dil, int prec, int epi);
 // THE split-K decision of gemm_kernel launches (the launcher takes it; the engine's tile choice prices a launch with it,
 // so the estimate and the launch cannot disagree): for `tiles` output tiles of 128 rows x 64 NI frames, `nchunks` hand-over
 // chunks of K (kchunks / KS), a workspace of ws_floats / ws_cnt_n: the number of K slices and the modelled time.
-// Model (fp32, fitted to 3..8 guided clips of 125 frames, tools/small_batch_ab.py): equal blocks run in lockstep rounds
+// Model (fp32, fitted to 3..8 guided clips of 125 frames, tools/lab/small_batch_ab.py): equal blocks run in lockstep rounds
 // over the 256 CUs - rounds x t_full / ks + exchange, t_full = a full-K tile (MFMA count x 69 cycles at 2.4 GHz), the
 // exchange (store, ticket, the last arriver's ordered re-read) ~(4 + ks) us.  Inside one resident round more slices are
 // always taken; beyond it a split must win by 3 %.

@@ -153,11 +153,14 @@ def test_fused_stack_soak_under_uneven_load():
                                           ("1", ["--T", "250", "--reps", "200"]),
                                           ("2", ["--T", "640", "--reps", "200"]),                    # five 128-frame tiles per clip: 40-block groups
                                           ("2", ["--T", "500", "--chain", "6", "--reps", "40"]),     # chains: the tail kernel too
-                                          ("1", ["--T", "250", "--chain", "6", "--reps", "40"])])
+                                          ("1", ["--T", "250", "--chain", "6", "--reps", "40"]),
+                                          ("5", ["--T", "640", "--reps", "200"]),                    # four 160-frame tiles per clip: 32-block groups
+                                          ("5", ["--T", "640", "--k", "15", "--reps", "60"]),        # BASELINE config 5: halo 56 frames
+                                          ("5", ["--T", "640", "--chain", "6", "--reps", "40"])])    # ... with the tail kernel (96-frame T4 items)
 def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
     """tools/xcd_stress.py: the full-depth (15-layer) full-width net with 32- / 64-block groups, block mapping 0 (every
     group spread over all eight XCDs: every hand-off crosses XCDs, and the X tiles of a conv phase arrive from memory
-    instead of the local L2) against mapping 1, bit for bit, >= 200 persistent launches per flavour (128- and 64-frame
+    instead of the local L2) against mapping 1, bit for bit, >= 200 persistent launches per flavour (128-, 64- and 160-frame
     blocks; whole chains bring the tail kernel in).  This is the class of test that exposed the missing
     wait before the LDS-DMA hand-over barrier in round 3 (25 % of the runs of the then 160-frame flavour)."""
     import os, subprocess, sys
@@ -172,11 +175,12 @@ def test_cross_xcd_handoffs_of_a_deep_net_are_bitwise_repeatable(flavour, args):
 
 
 def test_fused_chain_soak_is_bitwise_repeatable_at_the_bench_geometries():
-    """tools/fused_soak.py: 6 captured 200-step chains each at BASELINE config 2 (128-frame blocks) and config 3 (64-frame
-    blocks) - 2 x 1200 fused + tail launches - must give bit-identical rolls, without a barrier time-out."""
+    """tools/fused_soak.py: 6 captured 200-step chains each at BASELINE config 2 (128-frame blocks), config 3 (64-frame
+    blocks) and the reference's 640-frame shipping geometry (config 6: 160-frame blocks) - 3 x 1200 fused + tail launches -
+    must give bit-identical rolls, without a barrier time-out."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for cfg in ("2", "3"):
+    for cfg in ("2", "3", "6"):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "fused_soak.py"), "--chains", "6", "--config", cfg],
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (cfg, r.stdout[-1500:], r.stderr[-2000:])

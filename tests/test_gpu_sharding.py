@@ -266,11 +266,11 @@ def _fake_kfd_tree(root, busy):
         return False
     gids = []
     for nd in os.listdir(real):
-        try:
+        try:                                             # (inside a 1-GPU lease only the leased GPU's node is readable)
             gid = open(f"{real}/{nd}/gpu_id").read().strip()
             props = open(f"{real}/{nd}/properties").read()
         except OSError:
-            return False
+            continue
         d = os.path.join(root, "topology", "nodes", nd)
         os.makedirs(d)
         open(os.path.join(d, "gpu_id"), "w").write(gid + "\n")

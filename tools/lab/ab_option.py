@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Interleaved A/B of one engine option on whole captured chains:  python tools/ab_option.py fused_stack_warm 0 1 [--config 2] [--rounds 4]"""
+"""Interleaved A/B of one engine option on whole captured chains:  python tools/lab/ab_option.py fused_stack_warm 0 1 [--config 2] [--rounds 4]"""
 import argparse
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 

@@ -3,7 +3,7 @@
 prints wall per step; use under rocprofv3 --kernel-trace for per-kernel numbers."""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Whole-chain time of the five BASELINE.json configs at their PER-GPU shapes on one MI355X
 (graph-captured chain incl. front-end, Philox noise, random-init weights).
-    python tools/config_bench.py [--only 2,5]"""
+    python tools/lab/config_bench.py [--only 2,5]"""
 import argparse
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 

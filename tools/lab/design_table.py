@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Rewrite the numeric cells of DESIGN.md's per-configuration table from profiles/<round>_bench_cfgN.json (the narrative
-parts of the rows stay as they are):    python tools/design_table.py [r03]"""
+parts of the rows stay as they are):    python tools/lab/design_table.py [r03]"""
 import json
 import os
 import re
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PREFIX = {1: '| 1: k=9, 50 steps, B=1', 2: '| 2: k=9, 200 steps, B=16', 3: '| 3/GPU: k=9, generation', 4: '| 4/GPU: k=9, inpainting',
           5: '| 5/GPU: k=15, B=4', 6: '| 6: **the reference', 7: '| 7: config 3 at the reference'}
 

@@ -3,7 +3,7 @@
 queue as the GPU drains it), how much CPU does one chain cost, and does that change when 8 processes do it at once on
 one host (the 8-rank layout; on this 1-GPU box the 8 processes time-slice the GPU, so only HOST numbers are
 meaningful in that leg).
-    python tools/host_feed.py [--config 2] [--procs 8] [--chains 3]"""
+    python tools/lab/host_feed.py [--config 2] [--procs 8] [--chains 3]"""
 import argparse
 import json
 import os
@@ -11,7 +11,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 

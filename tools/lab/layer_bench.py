@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused dilated-conv+gate kernel (dr_bench_layer) on one MI355X.
-    python tools/layer_bench.py [--k 9] [--B 16] [--T 125] [--iters 50] [--layers 0,1,2,3]
+    python tools/lab/layer_bench.py [--k 9] [--B 16] [--T 125] [--iters 50] [--layers 0,1,2,3]
 Prints per-layer mean launch time (HIP events) and achieved TFLOP/s."""
 import argparse
 import os
@@ -8,7 +8,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 

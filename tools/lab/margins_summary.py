@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Aggregate a DR_PARITY_LOG file (one line per maxdiff() comparison of the GPU suite, plus the trained-regime battery's
-records) into the table committed under profiles/:  python tools/margins_summary.py <margins.txt> > profiles/rNN_parity_margins.txt"""
+records) into the table committed under profiles/:  python tools/lab/margins_summary.py <margins.txt> > profiles/rNN_parity_margins.txt"""
 import collections
 import re
 import statistics

@@ -1,6 +1,6 @@
 // Practical fp32-MFMA ceiling on this box: pure v_mfma_f32_32x32x2_f32 loop on random vs zero register
 // data, 1 or 2 waves per SIMD; reports TFLOP/s (wall) and the effective shader clock (s_memtime / wall).
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Sample socket power and shader clock (rocm-smi) while a chain runs:  bash tools/power_probe.sh [f32|bf16x3] [config]
+# Sample socket power and shader clock (rocm-smi) while a chain runs:  bash tools/lab/power_probe.sh [f32|bf16x3] [config]
 PREC=${1:-f32}
 CFG=${2:-2}
 python - "$PREC" "$CFG" <<'PY' &

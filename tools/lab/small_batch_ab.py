@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Chain time of small guided batches (the launches the under-filled kernel choices apply to), for A/B runs under
-different tune.* options:    DR_TEST_TUNE=tune.pwk=0 python tools/small_batch_ab.py [--batches 1,2,3,4,6] [--T 125] [--steps 50]"""
+different tune.* options:    DR_TEST_TUNE=tune.pwk=0 python tools/lab/small_batch_ab.py [--batches 1,2,3,4,6] [--T 125] [--steps 50]"""
 import argparse
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tools import tuning_env  # noqa: E402
 
