@@ -96,7 +96,10 @@ int shared_with_another_process(dr_engine* e, bool force = false, bool may_sync 
     TenantScan t = scan_tenants(root, e->kfd_gpu_id);
     if (!t.readable) return -1;
     if (!(t.holders >= 2 && t.busy_cus > 0)) return 0;
-    if (!may_sync) return -1;           // (undecided: what is busy may be this process's own other engines)
+    if (!may_sync) {                    // (undecided: what is busy may be this process's own other engines)
+        e->last_tenant_scan_s = 0;      // the look in front of the engine's first chain decides, whatever the rate limit says
+        return -1;
+    }
     (void)hipDeviceSynchronize();
     t = scan_tenants(root, e->kfd_gpu_id);
     return (t.holders >= 2 && t.busy_cus > 0) ? 1 : 0;

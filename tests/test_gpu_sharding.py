@@ -299,6 +299,8 @@ def test_engine_yields_to_a_busy_co_tenant_and_comes_back(tmp_path):
     if not (_fake_kfd_tree(busy, True) and _fake_kfd_tree(idle, False)):
         pytest.skip("no readable /sys/class/kfd/kfd/topology in this container")
     lib = _cabi.load_library()
+    import gc
+    gc.collect()                                          # engines of earlier tests
     lib.dr_debug_kfd_root(busy.encode())
     try:
         hp, p, m = _model(layers=3, steps=8, C=512)
@@ -308,7 +310,9 @@ def test_engine_yields_to_a_busy_co_tenant_and_comes_back(tmp_path):
         x = torch.randn(B, 1, Tn, 88)
         eng = m.engine
         st = eng.launch_state()
-        assert st["yields"] == 1 and st["fused_enabled"] == 0 and eng.yields == 1, st
+        # (the only engine of the process on the device decides at creation; with engines of earlier tests still alive the
+        # look at creation may not wait for THEIR work and stays undecided - the look in front of the first chain decides)
+        assert st["yields"] in (0, 1) and st["fused_enabled"] == 1 - st["yields"] and eng.yields == st["yields"], st
         a = m.sample(x, wav, seed=2)[0]
         st = eng.launch_state()
         assert st["mode"] == "per_phase" and st["yields"] == 1 and st["fallbacks"] == 0 and st["rearms"] == 0, st

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerate the rocprofv3 evidence under profiles/ - run ON THE GPU BOX:
-#     gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh r04 gpurun_out/prof'
+#     gpurun --timeout 3600 -- 'bash tools/refresh_profiles.sh r06 gpurun_out/prof'
 # then copy gpurun_out/prof/<round>_* into profiles/.  Counter passes are separate runs (one TCC-heavy counter set per
 # pass) and never combined with tracing other than --kernel-trace; every profiler call is bounded.
 set -u
-RD=${1:-r05}
+RD=${1:-r06}
 R=$PWD
 OUT=$R/${2:-gpurun_out/prof}
 mkdir -p "$OUT"
@@ -13,14 +13,14 @@ cd /tmp
 PS="python $R/tools/prof_summary.py"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/bench_kt.log" 2>&1
 echo "kernel trace rc=$?"
-$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, config 2: TWO launches per reverse step - stack_kernel<NI> = fused residual stack, 14 dilated convs + 15 1x1 per launch; tail_kernel = skip / output projection + combine + update + next input projection + next shared first-layer conv; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log - those rows are the front-end, each chain's first input projection / first-layer conv, and the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
+$PS "$OUT/kt" bench "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, config 2: TWO launches per reverse step - stack_kernel<FL> = fused residual stack, 14 dilated convs + 15 1x1 per launch; tail_kernel = skip / output projection + combine + update + next input projection + next shared first-layer conv; gemm_kernel<NI, KS, EPI, PREC>: EPI 0 plain 1 relu 2 silu 3 gate(conv) 4 res_skip 5 power 6 log - those rows are the front-end, each chain's first input projection / first-layer conv, and the event-instrumented roofline pass)" > "$OUT/${RD}_kernel_stats.txt"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt1" -o bench -- python "$R/bench.py" --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline > "$OUT/bench_kt1.log" 2>&1
 $PS "$OUT/kt1" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config 1 --steps 5 --warmup 2 --no-cpu-baseline --no-split --no-cold-start --no-roofline (MI355X, config 1: ONE 4-s clip, 50 steps, guided: per-phase launches with split-K)" > "$OUT/${RD}_kernel_stats_cfg1.txt"
 rm -rf "$OUT/kt1"
 # the other BASELINE configurations at their per-GPU shape: share_of_step_time of every bench line is reproducible from these
-for c in 3 4 5; do
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktc$c" -o bench -- python "$R/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/bench_kt$c.log" 2>&1
-$PS "$OUT/ktc$c" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, BASELINE config $c at its per-GPU shape; 3 timed-or-warm-up graph chains + the event-instrumented eager roofline pass)" > "$OUT/${RD}_kernel_stats_cfg$c.txt"
+for c in 3 4 5 6 7; do
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ktc$c" -o bench -- python "$R/bench.py" --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/bench_kt$c.log" 2>&1
+$PS "$OUT/ktc$c" bench "rocprofv3 --kernel-trace --stats -- python bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-cold-start (MI355X, bench config $c at its per-GPU shape - 3 / 4 / 5 = the BASELINE configurations, 6 / 7 = the reference's 640-frame shipping geometry; 3 timed-or-warm-up graph chains + the event-instrumented eager roofline pass)" > "$OUT/${RD}_kernel_stats_cfg$c.txt"
 rm -rf "$OUT/ktc$c"
 done
 for cfg in 1 2 3 4 5 6 7; do
@@ -49,7 +49,11 @@ rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
 timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
 timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"
 timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
+timeout 600 python tools/stack_check.py --config 5 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg5.txt"
+timeout 600 python tools/stack_check.py --config 6 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg6.txt"
 timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" --scale-json "$OUT/${RD}_scale.json" > "$OUT/${RD}_scale_table.txt" 2>&1
+# plumbing record of the N > 1 path on the one leased GPU (gloo, every rank on device 0, per-phase launches): one launch mode per rank
+timeout 900 python tools/scale_table.py --share-gpu --gpus 1,2,4,8 --configs 1 --steps 2 --out "$OUT/${RD}_scale_share_gpu_plumbing.json" > "$OUT/${RD}_scale_share_gpu_plumbing.txt" 2>&1
 # time-to-first-roll: round-3 behaviour re-enabled ("before") next to the current build, fresh process each
 { for c in 1 2; do timeout 300 python -m diffroll_amd.coldstart --config $c --json --tune tune.pack_threads=1 --tune tune.s3_eager=1 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "before (serial packing, eager split-bf16 packings)", "record": /; s/$/}/'; done
   for c in 1 2; do timeout 300 python -m diffroll_amd.coldstart --config $c --json 2>/dev/null | grep COLD_START | sed 's/^COLD_START /{"mode": "now", "record": /; s/$/}/'; done; } > "$OUT/${RD}_cold_start.json"

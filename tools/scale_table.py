@@ -93,6 +93,18 @@ def scale_record(table, gpus, configs):
     return rec
 
 
+def _modes(j):
+    """per-rank launch modes of a bench line, run-length: 'fused_stack+tail x8'"""
+    modes = j.get("per_rank_launch_mode") or []
+    out = []
+    for m in modes:
+        if out and out[-1][0] == m:
+            out[-1][1] += 1
+        else:
+            out.append([m, 1])
+    return ", ".join(f"{m} x{n}" for m, n in out) or "?"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", default="1,2,4,8")
@@ -125,7 +137,8 @@ def main():
             speedup = j["value"] / base
             print(f"{c:>6} {j['n_gpus']:>4} {j['value']:>10.1f} {j['ms_per_step']:>9.1f} {pr.get('min', 0):>9.1f} "
                   f"{pr.get('max', 0):>9.1f} {j.get('gather_us', 0):>9.1f} {speedup:>8.2f} {speedup / j['n_gpus']:>6.3f}  "
-                  f"{j['dist']['backend'] or 'single process'}, {j['dist']['ranks_seen']} rank(s), {j['_wall_s']} s wall")
+                  f"{j['dist']['backend'] or 'single process'}, {j['dist']['ranks_seen']} rank(s), {j['_wall_s']} s wall, "
+                  f"launch modes {_modes(j)}, yields {j.get('fused_yields', '?')}")
     if args.out:
         with open(args.out, "w") as f:
             json.dump(table, f, indent=1)
