@@ -352,6 +352,27 @@ def test_bench_refuses_to_print_a_line_when_the_engine_yielded(tmp_path):
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
     assert j["fused_yields"] == 0 and j["fused_fallbacks"] == 0 and j["launch_mode"] == "fused_stack+tail", j
+    assert j["attempts"] == 1 and j["discarded_attempts"] == [] and j["yields_since_creation"] == [0], j
+
+
+def test_bench_repeats_a_discarded_attempt_once_the_co_tenant_is_gone(tmp_path):
+    """A timed region that started on a yielded engine is discarded by all ranks and repeated: once the made-up co-tenant
+    idles (DR_BENCH_FAKE_KFD_THEN), the repeat's warm-up takes the two clean looks that switch the fused launches back on,
+    and the line that is printed says so: attempts 2, one discarded attempt, no yield inside the accepted timed region."""
+    import json
+    busy, idle = str(tmp_path / "busy"), str(tmp_path / "idle")
+    if not (_fake_kfd_tree(busy, True) and _fake_kfd_tree(idle, False)):
+        pytest.skip("no readable /sys/class/kfd/kfd/topology in this container")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "3", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+           "--no-split", "--no-roofline", "--no-cold-start"]
+    r = subprocess.run(cmd, env=dict(_clean_env(), DR_BENCH_FAKE_KFD=busy, DR_BENCH_FAKE_KFD_THEN=idle), capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "attempt 1 of 3 discarded" in r.stderr, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    assert j["attempts"] == 2 and len(j["discarded_attempts"]) == 1 and j["discarded_attempts"][0]["per_rank_launch_mode"] == ["per_phase"], j
+    assert j["fused_yields"] == 0 and j["fused_fallbacks"] == 0 and j["launch_mode"] == "fused_stack+tail", j
+    assert j["yields_since_creation"] == [1], j
 
 
 def test_scale_table_emits_a_scale_record_for_one_and_two_ranks(tmp_path):
