@@ -29,11 +29,21 @@ class _Stub:
     """Inert stand-in for an instance of a class that cannot be imported."""
     _dr_module = "?"
     _dr_name = "?"
+    # (class-level defaults: pickle's NEWOBJ path - every plain object pickled with protocol >= 2 - creates the instance
+    # with __new__ and never runs __init__)
+    _dr_args = ()
+    _dr_kwargs = {}
+    _dr_state = None
+
+    def __new__(cls, *args, **kwargs):
+        self = object.__new__(cls)
+        self._dr_args = args
+        self._dr_kwargs = kwargs
+        return self
 
     def __init__(self, *args, **kwargs):
         self._dr_args = args
         self._dr_kwargs = kwargs
-        self._dr_state = None
 
     def __setstate__(self, state):
         self._dr_state = state
@@ -184,6 +194,8 @@ def to_plain(obj: Any, _depth: int = 0) -> Any:
                 return to_plain(val, _depth)
             if "_value_" in state:                      # enum members
                 return to_plain(state["_value_"], _depth)
+            if _depth <= 16:                            # any other object (argparse.Namespace, a dataclass): its attributes
+                return {k: to_plain(v, _depth + 1) for k, v in state.items() if isinstance(k, str) and not k.startswith("_")}
         if obj._dr_args:                                # e.g. enums reduced to (value,)
             return to_plain(obj._dr_args[0], _depth) if len(obj._dr_args) == 1 else [to_plain(a, _depth) for a in obj._dr_args]
         return None

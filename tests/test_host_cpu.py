@@ -300,6 +300,38 @@ def test_checkpoint_that_names_os_system_loads_to_a_stub_and_executes_nothing(tm
     assert os.path.exists(marker)
 
 
+class _PlainHparams:
+    """module-level, so that pickle stores it BY REFERENCE (the loader must then cope with a class it never imports)"""
+    def __init__(self):
+        self.kernel_size = 9
+        self.nested = {"w": [0.5, 1]}
+        self._private = "dropped"
+
+
+def test_checkpoint_objects_created_without_init_become_plain_dicts(tmp_path):
+    """Every ordinary object pickles through NEWOBJ (protocol >= 2): the unpickler calls cls.__new__ and never __init__.  The
+    stand-in for a class that is not imported has to work on that path (it raised AttributeError before round 6's fix) and
+    reads as the object's public attributes; argparse.Namespace - what older Lightning versions store hparams as - and enum
+    members likewise; in both serialisation formats of torch.save."""
+    import argparse
+    import enum
+    from diffroll_amd.checkpoint import load_checkpoint
+
+    Colour = enum.Enum("Colour", {"RED": 3})
+    Colour.__module__, Colour.__qualname__ = __name__, "Colour"
+    globals()["Colour"] = Colour
+    hp = {"obj": _PlainHparams(), "ns": argparse.Namespace(timesteps=200, sampling={"type": "cfdg_ddpm_x0"}), "e": Colour.RED, "n": 3}
+    sd = {"w": torch.randn(3), "h": torch.randn(2).half(), "i": torch.arange(3)}
+    for legacy in (False, True):
+        path = str(tmp_path / f"plain{int(legacy)}.ckpt")
+        torch.save({"state_dict": sd, "hyper_parameters": hp}, path, _use_new_zipfile_serialization=not legacy)
+        ck = load_checkpoint(path)
+        assert ck["hyper_parameters"] == {"obj": {"kernel_size": 9, "nested": {"w": [0.5, 1]}},
+                                          "ns": {"timesteps": 200, "sampling": {"type": "cfdg_ddpm_x0"}}, "e": 3, "n": 3}
+        for k, v in sd.items():
+            assert torch.equal(ck["state_dict"][k], v) and ck["state_dict"][k].dtype == v.dtype
+
+
 def test_checkpoint_interpolations_resolve_against_the_root(tmp_path):
     """Real reference checkpoints carry spec_args = cfg.spec.args with `sample_rate: ${sampling_rate}` and
     `hop_length: ${hop_length}` (config/spec/mel.yaml, train_spec_roll.py:30): the pickled value nodes hold those
