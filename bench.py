@@ -286,6 +286,23 @@ def cpu_baseline(model, cfg, hp, budget_s=12.0, max_steps=40):
     }
 
 
+def rank_state(before, after, expect_fused, mode_code):
+    """One rank's verdict words for a timed region, from dr_launch_state before and after it: [fused time-outs healed inside
+    it, yields inside it, launch mode code, fusing throughout (or never meant to: an A/B run with the fused launches switched
+    off on purpose), yields since engine creation]."""
+    fusing = (not expect_fused) or (before["fused_enabled"] != 0 and after["fused_enabled"] != 0)
+    return [after["fallbacks"] - before["fallbacks"], after["yields"] - before["yields"], mode_code[after["mode"]], int(fusing),
+            after["yields"]]
+
+
+def degraded_ranks(states, share_gpu):
+    """[(rank, words)] of the ranks whose timed region is no measurement of the fused engine (collective verdict: one of them
+    is enough to discard the attempt on every rank).  --share-gpu runs ask for per-phase launches themselves: exempt."""
+    if share_gpu:
+        return []
+    return [(r, sx) for r, sx in enumerate(states) if sx[0] or sx[1] or not sx[3]]
+
+
 def _modes():
     from diffroll_amd import _cabi
     return dict(_cabi.MODES)
@@ -416,9 +433,7 @@ def main():
         st1 = model.engine.launch_state()
         dt, out = timed(args.steps)
         st = model.engine.launch_state()
-        mine = torch.tensor([st["fallbacks"] - st1["fallbacks"], st["yields"] - st1["yields"], mode_code[st["mode"]],
-                             int(not expect_fused or (st1["fused_enabled"] != 0 and st["fused_enabled"] != 0)), st["yields"]],
-                            device=cdev, dtype=torch.int64)
+        mine = torch.tensor(rank_state(st1, st, expect_fused, mode_code), device=cdev, dtype=torch.int64)
         if dist is not None:
             allst = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allst, mine)
@@ -426,7 +441,7 @@ def main():
         else:
             states = [[int(v) for v in mine.tolist()]]
         modes = [_modes()[sx[2]] for sx in states]
-        bad = [] if launch.share_gpu() else [(r, sx) for r, sx in enumerate(states) if sx[0] or sx[1] or not sx[3]]
+        bad = degraded_ranks(states, launch.share_gpu())
         if not bad:
             break
         why = "; ".join(f"rank {r}: {sx[0]} fused time-out(s) and {sx[1]} yield(s) to per-phase launches in the timed region, "

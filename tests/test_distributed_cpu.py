@@ -189,3 +189,33 @@ def test_share_gpu_mode_switches_the_group_to_gloo_and_host_tensors(monkeypatch)
             return "nccl"
     assert launch.collective_device(_Gloo, torch.device("cuda", 0)) == torch.device("cpu")
     assert launch.collective_device(_Nccl, torch.device("cuda", 0)) == torch.device("cuda", 0)
+
+
+def test_bench_attempt_verdict_is_collective_and_spares_deliberate_per_phase_runs():
+    """bench.py's discard rule, as pure logic: a timed region counts only if NO rank healed a time-out or
+    yielded inside it and every rank that was meant to fuse did so at both ends; an engine whose fused launches were switched
+    off on purpose (A/B) is not degraded; --share-gpu runs are exempt."""
+    import bench
+    code = {"per_phase": 1, "fused_stack": 2, "fused_stack+tail": 3, "none": 0}
+    clean = dict(fused_enabled=1, fallbacks=0, yields=0, mode="fused_stack+tail")
+    good = bench.rank_state(clean, clean, True, code)
+    assert good == [0, 0, 3, 1, 0] and bench.degraded_ranks([good] * 8, False) == []
+    # a yield inside the timed region on rank 5 of 8: everybody discards
+    y = bench.rank_state(clean, dict(clean, yields=1, fused_enabled=0, mode="per_phase"), True, code)
+    assert y[:4] == [0, 1, 1, 0]
+    bad = bench.degraded_ranks([good] * 5 + [y] + [good] * 2, False)
+    assert [r for r, _ in bad] == [5]
+    # yielded at creation, never came back: nothing moves inside the timed region, still no measurement
+    stuck = dict(fused_enabled=0, fallbacks=0, yields=1, mode="per_phase")
+    assert bench.degraded_ranks([bench.rank_state(stuck, stuck, True, code)], False) != []
+    # yielded in the warm-up and re-armed before the timed region: fine (yields since creation stay visible)
+    back = dict(fused_enabled=1, fallbacks=0, yields=1, mode="fused_stack+tail")
+    w = bench.rank_state(back, back, True, code)
+    assert bench.degraded_ranks([w], False) == [] and w[4] == 1
+    # a healed time-out inside the region
+    t = bench.rank_state(clean, dict(clean, fallbacks=1, fused_enabled=0, mode="per_phase"), True, code)
+    assert bench.degraded_ranks([good, t], False)[0][0] == 1
+    # fused launches switched off on purpose / --share-gpu
+    off = dict(fused_enabled=0, fallbacks=0, yields=0, mode="per_phase")
+    assert bench.degraded_ranks([bench.rank_state(off, off, False, code)], False) == []
+    assert bench.degraded_ranks([y, t], True) == []
