@@ -49,8 +49,13 @@ rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
 timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
 timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"
 timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
-timeout 600 python tools/stack_check.py --config 5 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg5.txt"
-timeout 600 python tools/stack_check.py --config 6 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg6.txt"
+# (160-frame flavour: the per-phase launches are pinned to its twins - gemm_kernel<5>, no split-K, the five-tile 1x1 - as
+# tests/test_gpu_fused.py does, so that "bitwise_equal" compares like with like; the natural per-phase choice is what
+# profiles/*_stack160_ab.txt times)
+for c in 5 6; do
+  { echo "# DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3205,tune.pw_nw=5 python tools/stack_check.py --config $c"
+    DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3205,tune.pw_nw=5 timeout 600 python tools/stack_check.py --config $c 2>&1 | grep -v "rep [12]" | grep -v amdgpu.ids; } > "$OUT/${RD}_stack_phase_ticks_cfg$c.txt"
+done
 timeout 900 python tools/scale_table.py --gpus 1,2,4,8 --configs 2,3,4,5 --steps 2 --out "$OUT/${RD}_scale_table.json" --scale-json "$OUT/${RD}_scale.json" > "$OUT/${RD}_scale_table.txt" 2>&1
 # plumbing record of the N > 1 path on the one leased GPU (gloo, every rank on device 0, per-phase launches): one launch mode per rank
 timeout 900 python tools/scale_table.py --share-gpu --gpus 1,2,4,8 --configs 1 --steps 2 --out "$OUT/${RD}_scale_share_gpu_plumbing.json" > "$OUT/${RD}_scale_share_gpu_plumbing.txt" 2>&1
