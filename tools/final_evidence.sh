@@ -18,7 +18,7 @@ python tools/lab/margins_summary.py "$O/margins_raw.txt" > "$O/${RD}_parity_marg
 echo "# the GPU suite with every engine's DEFAULTS changed (tools/tuning_env.py), one MI355X, round-6 final sources"
 for tune in fused_stack=0 tune.stack_fl=-5; do
   echo "##### DR_TEST_TUNE=$tune"
-  DR_TEST_TUNE=$tune timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -4
+  DR_TEST_TUNE=$tune timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|^FAILED|^ERROR"
 done
 } > "$O/${RD}_forced_mode_suites.txt" 2>&1
 cat "$O/${RD}_forced_mode_suites.txt"
