@@ -517,6 +517,42 @@ def test_frontend_tables_carry_the_reference_rounding():
     assert int((fb.sum(0) == 0).sum()) == 0     # no empty filter at the released settings
 
 
+def test_mel_front_end_agrees_with_an_independent_third_party_implementation():
+    """torchaudio is absent from this image, so the mel half of the front-end was pinned only from inside this
+    repository.  `transformers.audio_utils` IS installed and is an independent implementation of the same published
+    definitions (HTK mel scale, triangles in Hz, no area normalisation; periodic Hann; centred reflect-padded STFT, power
+    2) in float64 numpy: the window, the filterbank and the whole mel power spectrogram of the oracle / of the tables the
+    engine receives agree with it to fp32 rounding.  What stays unpinned is only torchaudio's own fp32 rounding PATTERN of
+    the filterbank (<= 2.2e-5 absolute), not its formula."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from diffroll_amd import frontend_tables as FT
+    from oracle import diffroll_ref as R
+    hp = dict(R.DEFAULT_HP)
+    n_fft, hop, bins = int(hp["n_fft"]), int(hp["hop_length"]), int(hp["n_fft"]) // 2 + 1
+    w, norm, fb = FT.frontend_tables(n_fft, hp["f_min"], hp["f_max"], hp["n_mels"], hp["sample_rate"])
+    ref_fb = au.mel_filter_bank(num_frequency_bins=bins, num_mel_filters=int(hp["n_mels"]), min_frequency=float(hp["f_min"]),
+                                max_frequency=float(hp["f_max"]), sampling_rate=int(hp["sample_rate"]), norm=None, mel_scale="htk")
+    assert ref_fb.shape == tuple(fb.shape)
+    assert np.abs(fb.double().numpy() - ref_fb).max() <= 3e-5
+    assert ((fb.numpy() > 0) == (ref_fb > 0)).mean() >= 0.9999       # same supports (a handful of fp32 edge cases at the corners)
+    ref_w = au.window_function(n_fft, "hann", periodic=True)
+    assert np.abs(ref_w - w.numpy()).max() <= 1e-6
+    # the mel power spectrogram of a clip: the oracle (torch.stft, fp32) against numpy's FFT in float64 with THEIR tables;
+    # torchaudio's normalized=True divides the spectrum by sqrt(sum w^2), i.e. the power by sum w^2
+    g = torch.Generator().manual_seed(17)
+    t = torch.arange(4 * 16000) / 16000.0
+    wav = 0.05 * torch.randn(1, t.numel(), generator=g) + 0.3 * torch.sin(2 * np.pi * 440.0 * t) + 0.1 * torch.sin(2 * np.pi * 3520.0 * t)
+    ours = R.mel_spectrogram(wav, hp)[0].double().numpy()                                   # (n_mels, frames)
+    theirs = au.spectrogram(wav[0].double().numpy(), ref_w, frame_length=n_fft, hop_length=hop, fft_length=n_fft, power=2.0,
+                            center=True, pad_mode="reflect", onesided=True, mel_filters=ref_fb, mel_floor=0.0,
+                            dtype=np.float64) / float((ref_w ** 2).sum())
+    assert theirs.shape == ours.shape == (int(hp["n_mels"]), t.numel() // hop + 1)
+    scale = theirs.max()
+    assert np.abs(ours - theirs).max() <= 2e-5 * scale, np.abs(ours - theirs).max() / scale
+    # ... and after the log the reference takes (model/diffwave.py:644): the quantity the conditioner consumes
+    assert np.abs(np.log(ours + 1e-6) - np.log(theirs + 1e-6)).max() <= 5e-4       # observed 2.0e-4 (2.6e-6 of the scale above)
+
+
 def test_resample_restates_torchaudio_011_windowed_sinc():
     """diffroll_amd.audio.resample = torchaudio.functional.resample with the 0.11 defaults (utils/custom_dataset.py:62):
     checked against an independent scalar evaluation of the published kernel formula, and by properties (length,
