@@ -436,6 +436,27 @@ def test_note_metrics_against_exhaustive_matching():
     assert (p, r) == (0.5, 1.0)
 
 
+def test_note_matching_size_against_scipy_on_realistic_note_counts():
+    """mir_eval counts a MAXIMUM bipartite matching of the hit graph (its size is unique whatever algorithm finds it): our
+    augmenting-path search against scipy.sparse.csgraph.maximum_bipartite_matching - an independent third-party
+    implementation of Hopcroft-Karp - on dense transcriptions of a few hundred notes with many competing candidates."""
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from diffroll_amd import metrics as M
+    rng = np.random.default_rng(11)
+    for n_ref, n_est in ((150, 170), (300, 260), (64, 400)):
+        ref_on = np.round(rng.integers(0, 400, n_ref) * 0.032, 6)
+        est_on = np.round(ref_on[rng.integers(0, n_ref, n_est)] + rng.integers(-2, 3, n_est) * 0.032, 6)       # 0, 1 or 2 frames off
+        ref_i, est_i = np.stack([ref_on, ref_on + 0.1], 1), np.stack([est_on, est_on + 0.1], 1)
+        ref_m, est_m = 21 + rng.integers(30, 36, n_ref), 21 + rng.integers(30, 36, n_est)
+        ref_p, est_p = M.midi_to_hz(ref_m), M.midi_to_hz(est_m)
+        hit = (np.abs(np.round(np.abs(ref_on[:, None] - est_on[None, :]), 6)) <= 0.05) & (ref_m[:, None] == est_m[None, :])
+        size = int((maximum_bipartite_matching(csr_matrix(hit.astype(np.int8)), perm_type="column") >= 0).sum())
+        assert 0 < size < min(n_ref, n_est)                     # a case with real competition
+        p, r, f = M.evaluate_notes(ref_i, ref_p, est_i, est_p)
+        assert abs(p - size / n_est) < 1e-12 and abs(r - size / n_ref) < 1e-12 and abs(f - 2 * p * r / (p + r)) < 1e-12
+
+
 def test_extra_beta_schedules_bit_equal(golden_dir):
     """cosine / quadratic / sigmoid beta schedules (model/unet.py:558-579) == the reference's outputs, and
     make_schedule(betas=...) feeds them through the same table builder."""
