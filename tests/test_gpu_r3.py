@@ -96,7 +96,8 @@ def test_two_engines_on_two_streams_both_match_the_oracle():
     # nobody ran into the ~1 s spin bound and nobody yielded: the engines take turns on the device's fused slot
     assert [m.engine.fallbacks for m in models] == [0, 0]
     assert [m.engine.yields for m in models] == [0, 0]
-    assert [m.engine.launch_state()["mode"] for m in models] == ["fused_stack+tail"] * 2
+    fused = __import__("tools.tuning_env").tuning_env.forced("fused_stack", 1) != 0      # (DR_TEST_TUNE="fused_stack=0": a forced-mode run of the suite)
+    assert [m.engine.launch_state()["mode"] for m in models] == ["fused_stack+tail" if fused else "per_phase"] * 2
     for i in range(2):
         for rnd in range(4):
             assert results[i][rnd] is not None
