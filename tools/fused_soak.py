@@ -39,8 +39,10 @@ def main():
     flag, _ = m.engine.stack_status()
     m.engine.set_option("fused_stack", 0)
     un, _ = m.sample(x, wav, seed=1)
+    # (the per-phase launches of this comparison are the planner's NATURAL choice - other tile widths, split-K: another fp32
+    # accumulation order, a few ulp; bit-identity against the per-phase TWINS of each flavour is tests/test_gpu_fused.py)
     print(f"config {args.config}: {args.chains} chains ({args.chains * cfg['S']} fused launches): mismatching chains {bad}, "
-          f"barrier time-outs {flag}, fused == per-phase launches: {bool(torch.equal(un, ref))}, "
+          f"barrier time-outs {flag}, max |fused - natural per-phase launches| {float((un - ref).abs().max()):.2e}, "
           f"fused launches captured {m.engine.stack_launches}")
     return 1 if (bad or flag) else 0
 
