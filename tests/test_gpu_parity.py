@@ -878,6 +878,56 @@ def test_random_full_width_geometries_vs_oracle():
         assert d <= ATOL_STEP, (case, hp["residual_layers"], hp["kernel_size"], sampler, B, Tn, precision, d)
 
 
+@pytest.mark.gpu
+def test_640_frame_family_picks_the_160_frame_stack_and_matches_the_oracle():
+    """Round 6: the planner's NATURAL choice at the 640-frame geometries is the fused residual stack on 160-frame blocks
+    (stack_kernel<5>): one resident round at 8 evaluations, balanced chunks beyond, nothing fused where a launch would leave
+    the chip part-filled.  One step and a short captured chain per case against the oracle, full width, k = 9 and 15; the
+    launch mode the engine reports is asserted where the geometry decides it."""
+    from tools import tuning_env
+    natural = not (tuning_env.is_forced("fused_stack") or tuning_env.is_forced("tune.stack_fl") or tuning_env.is_forced("fused_tail")
+                   or tuning_env.is_forced("blocked_accumulation"))
+    cases = [  # B, T, k, sampler, expected kernel prefix / mode under default options (None: not asserted)
+        (4, 640, 9, "cfdg_ddpm_x0", "stack_kernel<5>", "fused_stack+tail"),        # the reference's shipping geometry
+        (4, 640, 15, "cfdg_ddpm_x0", "stack_kernel<5>", "fused_stack+tail"),       # BASELINE config 5 per GPU
+        (8, 640, 9, "generation_ddpm_x0", "stack_kernel<5>", "fused_stack+tail"),  # 8 evaluations, one per clip
+        (16, 640, 9, "generation_ddpm_x0", "stack_kernel<5>", "fused_stack"),      # two chunks of 8: no tail kernel
+        (4, 600, 9, "cfdg_ddpm_x0", "stack_kernel<5>", "fused_stack+tail"),        # ragged last tile (120 of 160 frames)
+        (2, 640, 9, "cfdg_ddpm_x0", None, None),                                   # half the chip: the planner's split-K territory
+        (3, 800, 9, "ddpm_x0", None, None),                                        # 5 tiles per clip
+    ]
+    for (B, Tn, k, sampler, want_kernel, want_mode) in cases:
+        hp = dict(R.DEFAULT_HP)
+        hp.update(residual_layers=2, kernel_size=k, timesteps=4)
+        p = R.synthetic_params(hp, seed=640 + B + k)
+        m = make_model(hp, p, sampler=sampler, w=0.5)
+        sch = R.schedule(hp["beta_start"], hp["beta_end"], 4)
+        g = torch.Generator().manual_seed(B * 31 + Tn)
+        wav = 0.1 * torch.randn(B, Tn * 512, generator=g)
+        x = torch.randn(B, 1, Tn, 88, generator=g)
+        nz = torch.randn(4, B, 1, Tn, 88, generator=g)
+        with torch.no_grad():
+            spec = None if sampler == "generation_ddpm_x0" else R.frontend(wav, hp, Tn)
+            ref = R.reverse_step(p, hp, sch, sampler, x, spec, 2, nz[0], 0.5)
+            ref_chain = R.sample_chain(p, hp, sampler, x, None if sampler == "generation_ddpm_x0" else wav, nz, w=0.5)
+        eng = m.engine
+        eng.profile_enable(True)
+        out, _ = m.reverse_diffusion(x, wav, 2, noise=nz[0])
+        _, _, _, kname = eng.profile_read_ex()
+        eng.profile_enable(False)
+        d = maxdiff(out.cpu(), ref)
+        assert d <= ATOL_STEP, (B, Tn, k, sampler, d)
+        roll, _ = m.sample(x, wav, noise=nz)
+        d = maxdiff(roll.cpu(), ref_chain)
+        assert d <= ATOL_STEP, ("chain", B, Tn, k, sampler, d)
+        st = eng.launch_state()
+        assert st["fallbacks"] == 0 and st["yields"] == 0, st
+        if natural and want_kernel:
+            assert kname.startswith(want_kernel), (B, Tn, k, sampler, kname)
+            assert st["mode"] == want_mode, (B, Tn, k, sampler, st)
+        del m
+
+
 def test_random_chains_vs_oracle():
     """Randomised (fixed seed) whole chains through dr_sample (captured graph) against the oracle's loop: random
     depth / width / kernel size / schedule length, the four x0-prediction samplers and the DDIM / epsilon ones,
