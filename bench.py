@@ -19,7 +19,10 @@ clips, the only collective is the final all-gather.
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic FLOPs per launch / mean launch
 duration measured with HIP events on the launch stream in an extra, event-instrumented eager pass of the same
 chain run right after the timed region.  `cpu_baseline` is the CPU oracle (a port of the reference math, torch
-CPU fp32) timed on this box's host cores on a bounded sample.
+CPU fp32) timed on this box's host cores on a bounded sample.  `launch_mode` / `per_rank_launch_mode` / `fused_yields` /
+`fused_fallbacks` say what every rank's engine launched inside the timed region: a region in which any rank yielded to
+per-phase launches or healed a fused time-out is discarded by all ranks and repeated (`attempts`, `discarded_attempts`), at
+most twice - then there is no line and the exit code is not 0.
 """
 import argparse
 import hashlib
