@@ -47,8 +47,13 @@ done
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline --no-split --no-cold-start > "$OUT/${RD}_bench_cfg2_nccl_1rank.json" 2> "$OUT/bench_nccl.err"; echo "bench nccl rc=$?"
 rm -rf "$OUT/kt" "$OUT"/pf[1-7] "$OUT"/pw[1-7] "$OUT/pm" "$OUT/pl" profiles_tmp
 timeout 300 python tools/tail_ticks.py --config 2 > "$OUT/${RD}_tail_phase_ticks.txt" 2>&1
-timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks.txt"
-timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
+# (the per-phase launches of these comparisons are pinned to the fused flavour's TWINS - same conv tile width, no split-K, the
+# matching 1x1 - as tests/test_gpu_fused.py does, so that "bitwise_equal" compares like with like; the planner's natural
+# per-phase choice differs from any fused flavour by an ulp of accumulation order)
+{ echo "# DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3202,tune.pw_nw=4 python tools/stack_check.py --config 2"
+  DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3202,tune.pw_nw=4 timeout 600 python tools/stack_check.py --config 2 2>&1 | grep -v "rep [12]" | grep -v amdgpu.ids; } > "$OUT/${RD}_stack_phase_ticks.txt"
+{ echo "# DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3201,tune.pw_nw=2 python tools/stack_check.py --config 3"
+  DR_TEST_TUNE=tune.ksplit_max=1,tune.tile=3201,tune.pw_nw=2 timeout 600 python tools/stack_check.py --config 3 2>&1 | grep -v "rep [12]" | grep -v amdgpu.ids; } > "$OUT/${RD}_stack_phase_ticks_cfg3.txt"
 # (160-frame flavour: the per-phase launches are pinned to its twins - gemm_kernel<5>, no split-K, the five-tile 1x1 - as
 # tests/test_gpu_fused.py does, so that "bitwise_equal" compares like with like; the natural per-phase choice is what
 # profiles/*_stack160_ab.txt times)
