@@ -35,6 +35,11 @@ $PS "$OUT/pw2" pw "rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pm" -o pm -- python "$R/tools/step_loop.py" --config 2 --iters 10 > "$OUT/pm.log" 2>&1
 echo "mfma rc=$?"
 $PS "$OUT/pm" pm "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_mfma.txt"
+# ... and of the 160-frame flavour at the reference's shipping geometry (config 6)
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d "$OUT/pm6" -o pm -- python "$R/tools/step_loop.py" --config 6 --iters 10 > "$OUT/pm6.log" 2>&1
+echo "mfma cfg6 rc=$?"
+$PS "$OUT/pm6" pm "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -- python tools/step_loop.py --config 6 --iters 10" > "$OUT/${RD}_stack_pmc_mfma_cfg6.txt"
+rm -rf "$OUT/pm6"
 timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace --output-format csv -d "$OUT/pl" -o pl -- python "$R/tools/step_loop.py" --config 2 --iters 10 > "$OUT/pl.log" 2>&1
 echo "lds rc=$?"
 $PS "$OUT/pl" pl "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS --kernel-trace -- python tools/step_loop.py --config 2 --iters 10" > "$OUT/${RD}_stack_pmc_lds.txt"
